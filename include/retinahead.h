@@ -1,0 +1,241 @@
+/*
+ * retinahead.h - C ABI of libretinahead.so: the RetinaNet per-anchor dense-head
+ * path (anchors, IoU assignment, focal + smooth-L1 loss forward/backward, box
+ * decode/clip, score threshold + NMS) as hand-written gfx950 (MI355X) kernels.
+ *
+ * Conventions for every entry point
+ *   - Pointers named in the comments as "device" are raw HIP device pointers;
+ *     the library never allocates, frees or copies to the host.  Temporary
+ *     storage is a caller-owned workspace whose size the matching
+ *     *_workspace_bytes() query returns (align it to 256 bytes).
+ *   - `stream` is a hipStream_t (NULL = the default stream).  Work is enqueued
+ *     on it for the CALLER'S CURRENT DEVICE; nothing synchronises.
+ *   - Return value: RH_OK or a negative RH_E* code; rh_last_error() gives the
+ *     text for the calling thread.  Shapes are validated on the host before
+ *     any launch, so a bad argument never reaches a kernel.
+ *   - All tensors are dense, row-major float32 unless a comment says otherwise.
+ *   - Re-entrant: no mutable global state; safe from several host threads.
+ *
+ * The reference (mesnico/pytorch-retinanet) has no FFI: each entry point names
+ * the Python lines it stands in for.
+ */
+#ifndef RETINAHEAD_H
+#define RETINAHEAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_VERSION 100 /* 0.1.0 */
+
+typedef void* rh_stream_t; /* hipStream_t */
+
+enum rh_status {
+  RH_OK = 0,
+  RH_EINVAL = -1,     /* null pointer / bad scalar argument            */
+  RH_ESHAPE = -2,     /* unsupported or inconsistent shape             */
+  RH_ELAUNCH = -3,    /* HIP refused a launch                          */
+  RH_EWORKSPACE = -4, /* workspace missing or too small                */
+  RH_EALIGN = -5      /* pointer not aligned as the entry point needs  */
+};
+
+/* Per-anchor assignment states written by rh_assign (losses.py:70-72). */
+enum rh_anchor_state { RH_NEGATIVE = 0, RH_IGNORE = 1, RH_POSITIVE = 2 };
+
+/* Bits of the device status word written by the loss entry points. */
+enum rh_status_bits {
+  RH_STATUS_LABEL_RANGE = 1 /* a valid GT row has a label outside [0, C): the
+                               reference raises IndexError at losses.py:79; here
+                               the anchor is positive with an all-zero target row */
+};
+
+int rh_version(void);
+/* Copies the calling thread's last error text (NUL-terminated, truncated to cap);
+ * returns the untruncated length. */
+size_t rh_last_error(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------- *
+ * Anchors  -  replaces Anchors.forward, models/retinanet/anchors.py:22-41
+ * (generate_anchors :48-79, shift :115-135).
+ * ------------------------------------------------------------------------- */
+#define RH_MAX_LEVELS 8
+#define RH_MAX_RATIOS 8
+#define RH_MAX_SCALES 8
+typedef struct rh_anchor_cfg {
+  int32_t num_levels;
+  int32_t levels[RH_MAX_LEVELS];  /* pyramid level l: feature map = ceil(H/2^l) x ceil(W/2^l) */
+  double strides[RH_MAX_LEVELS];  /* default 2^l       (anchors.py:14) */
+  double sizes[RH_MAX_LEVELS];    /* default 2^(l+2)   (anchors.py:16) */
+  int32_t num_ratios;
+  double ratios[RH_MAX_RATIOS];   /* default 0.5, 1, 2 (anchors.py:18) */
+  int32_t num_scales;
+  double scales[RH_MAX_SCALES];   /* default 2^0, 2^(1/3), 2^(2/3) (anchors.py:20) */
+} rh_anchor_cfg;
+
+/* Fills *cfg with the reference defaults (levels 3..7). */
+void rh_anchor_cfg_default(rh_anchor_cfg* cfg);
+/* Number of anchors N for an H x W image, or a negative RH_E* code. */
+int64_t rh_anchor_count(const rh_anchor_cfg* cfg, int32_t height, int32_t width);
+/* out: device [N,4] (x1,y1,x2,y2), N = rh_anchor_count(...).  Values are formed
+ * in float64 and narrowed once, exactly like the numpy reference. */
+int rh_anchors_f32(const rh_anchor_cfg* cfg, int32_t height, int32_t width, float* out,
+                   int64_t n, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * IoU matrix  -  replaces calc_iou, models/retinanet/losses.py:6-23.
+ * a: device [n,4], b: device [m,4], out: device [n,m].
+ * ------------------------------------------------------------------------- */
+int rh_calc_iou_f32(const float* a, int64_t n, const float* b, int64_t m, float* out,
+                    rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Anchor assignment  -  replaces losses.py:48-49 (GT filter), :59-61 (IoU,
+ * max/argmax over GT, first index on ties), :70-79 (thresholds, one-hot label).
+ *   anchors      device [N,4]
+ *   annotations  device [B,M,5] (x1,y1,x2,y2,label), rows with label == -1 are padding
+ *   state        device u8 [B,N]   rh_anchor_state; an image without valid GT is all RH_IGNORE
+ *   argmax       device i32 [B,N]  index into the image's valid-GT list (order kept)
+ *   label        device i32 [B,N]  class of positives, -1 otherwise
+ *   iou_max      device f32 [B,N]
+ *   num_pos      device i32 [B]
+ * Any of state/argmax/label/iou_max may be NULL.  status: device i32 [1] or NULL.
+ * ------------------------------------------------------------------------- */
+size_t rh_assign_workspace_bytes(int32_t batch, int64_t n, int32_t m);
+int rh_assign(const float* anchors, const float* annotations, int32_t batch, int64_t n, int32_t m,
+              int32_t num_classes, float neg_thresh, float pos_thresh, uint8_t* state,
+              int32_t* argmax, int32_t* label, float* iou_max, int32_t* num_pos, int32_t* status,
+              void* workspace, size_t workspace_bytes, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Fused dense-head loss, forward + backward  -  replaces FocalLoss.forward,
+ * models/retinanet/losses.py:29-141, and the autograd graph it records.
+ *   classifications device [B,N,C]  post-sigmoid probabilities (model.py:177,193)
+ *   regressions     device [B,N,4]
+ *   anchors         device [N,4]    (the reference's [1,N,4])
+ *   annotations     device [B,M,5]
+ *   d_classifications device [B,N,C], d_regressions device [B,N,4]:
+ *       gradients of grad_cls*classification_loss + grad_reg*regression_loss
+ *   losses          device f32 [2]  {classification_loss, regression_loss} (batch means, :139-141)
+ *   per_image       device f32 [2,B] or NULL  (per-image losses, :94 and :134)
+ *   num_pos         device i32 [B] or NULL
+ *   status          device i32 [1] or NULL  (rh_status_bits, OR-ed in)
+ * batch_divisor: number of images the batch mean runs over; 0 means B.  A
+ * data-parallel shard passes the global batch size.
+ * ------------------------------------------------------------------------- */
+typedef struct rh_focal_params {
+  float alpha;          /* 0.25  losses.py:30 (gamma is fixed at 2, :31) */
+  float neg_thresh;     /* 0.4   losses.py:70 */
+  float pos_thresh;     /* 0.5   losses.py:72 */
+  float grad_cls;       /* upstream gradient of classification_loss */
+  float grad_reg;       /* upstream gradient of regression_loss     */
+  int32_t batch_divisor;
+} rh_focal_params;
+
+void rh_focal_params_default(rh_focal_params* p);
+
+/* Stages of the fused call, for profiling; RH_STAGE_ALL runs the whole path. */
+enum rh_focal_stage {
+  RH_STAGE_ASSIGN = 1,   /* GT compaction + IoU assignment + num_pos            */
+  RH_STAGE_STREAM = 2,   /* N x C focal stream + smooth-L1, losses and gradients */
+  RH_STAGE_FINALIZE = 4, /* deterministic reduction of the per-tile partial sums */
+  RH_STAGE_ALL = 7
+};
+
+size_t rh_focal_loss_workspace_bytes(int32_t batch, int64_t n, int32_t num_classes, int32_t m);
+int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions,
+                          const float* anchors, const float* annotations, int32_t batch, int64_t n,
+                          int32_t num_classes, int32_t m, const rh_focal_params* params,
+                          float* d_classifications, float* d_regressions, float* losses,
+                          float* per_image, int32_t* num_pos, int32_t* status, void* workspace,
+                          size_t workspace_bytes, int32_t stages, rh_stream_t stream);
+
+/* In-place x *= (*scale_dev) / assumed over count floats; returns without touching memory
+ * traffic when *scale_dev == assumed.  Used by the autograd wrapper to apply an upstream
+ * gradient (train.py:185-190) to the stored gradients without a host read. */
+int rh_scale_inplace_f32(float* x, int64_t count, const float* scale_dev, float assumed,
+                         rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Generic elementwise focal BCE, forward + backward  -  replaces
+ * FocalLoss.forward, models/focal_loss.py:14-25.
+ *   inputs, targets device [count]; loss_elem device [count] or NULL;
+ *   loss_mean device f32 [1] or NULL; grad device [count] (d/d inputs of the
+ *   mean when reduce != 0, of the sum of elements otherwise).
+ * ------------------------------------------------------------------------- */
+size_t rh_generic_focal_workspace_bytes(int64_t count);
+int rh_generic_focal_fwd_bwd(const float* inputs, const float* targets, int64_t count, float alpha,
+                             float gamma, int32_t logits, int32_t reduce, float* loss_elem,
+                             float* loss_mean, float* grad, void* workspace,
+                             size_t workspace_bytes, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Box decode and clip  -  replace BBoxTransform.forward (utils.py:96-120) and
+ * ClipBoxes.forward (utils.py:133-142).
+ *   boxes device [N,4] (broadcast over the batch), deltas device [B,N,4],
+ *   out device [B,N,4]; mean/std: host float[4] (NULL = 0,0,0,0 / .1,.1,.2,.2).
+ *   rh_clip_boxes_f32 works in place: x1,y1 >= 0, x2 <= width, y2 <= height.
+ * ------------------------------------------------------------------------- */
+int rh_bbox_transform_f32(const float* boxes, const float* deltas, int32_t batch, int64_t n,
+                          const float* mean, const float* std, float* out, rh_stream_t stream);
+int rh_clip_boxes_f32(float* boxes, int64_t rows, float width, float height, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * NMS  -  replaces torchvision.ops.nms as called at model.py:336 (greedy, drop
+ * when IoU > iou_threshold, ties in score keep the lower index first).
+ *   boxes device [K,4], scores device [K], labels device i32 [K] or NULL
+ *   (non-NULL: only equal labels suppress each other),
+ *   keep device i64 [K] (first *keep_count entries valid, descending score),
+ *   keep_count device i32 [1].
+ * ------------------------------------------------------------------------- */
+size_t rh_nms_workspace_bytes(int64_t k);
+int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64_t k,
+           float iou_threshold, int64_t* keep, int32_t* keep_count, void* workspace,
+           size_t workspace_bytes, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Inference post-processing for a batch  -  replaces model.py:320-340 (which
+ * handles image 0 only) for every image of the batch.
+ *   classifications device [B,N,C], regressions device [B,N,4], anchors device [N,4]
+ *   cand_cap  : capacity of the per-image candidate list (anchors with
+ *               max-class score > score_thresh).  Candidates beyond it are
+ *               dropped and counted in overflow[b]; cand_cap = N can never overflow.
+ *   per_class : 0 = class-agnostic NMS (the reference), 1 = only equal labels suppress
+ *   pre_nms_topk : > 0 keeps only the best-scoring candidates before NMS
+ *   max_det   : > 0 truncates each image's kept list
+ *   out_scores device f32 [B,out_cap], out_labels device i64 [B,out_cap],
+ *   out_boxes device f32 [B,out_cap,4], out_count device i32 [B],
+ *   cand_count device i32 [B] or NULL, overflow device i32 [B] or NULL.
+ *   out_cap = max_det if max_det > 0, else min(cand_cap, pre_nms_topk or cand_cap).
+ * ------------------------------------------------------------------------- */
+typedef struct rh_post_params {
+  float height, width;   /* image size used by the clip (utils.py:134) */
+  float score_thresh;    /* 0.05 model.py:325 */
+  float iou_thresh;      /* 0.5  model.py:336 */
+  int32_t per_class;
+  int32_t pre_nms_topk;
+  int32_t max_det;
+  int32_t cand_cap;
+} rh_post_params;
+
+size_t rh_postprocess_workspace_bytes(int32_t batch, int64_t n, int32_t num_classes,
+                                      const rh_post_params* params);
+int rh_postprocess(const float* classifications, const float* regressions, const float* anchors,
+                   int32_t batch, int64_t n, int32_t num_classes, const rh_post_params* params,
+                   float* out_scores, int64_t* out_labels, float* out_boxes, int32_t* out_count,
+                   int32_t* cand_count, int32_t* overflow, void* workspace,
+                   size_t workspace_bytes, int32_t stages, rh_stream_t stream);
+
+enum rh_post_stage {
+  RH_POST_DECODE = 1, /* class max + threshold + decode + clip + compaction */
+  RH_POST_SORT = 2,   /* per-image sort by (score desc, anchor index asc)   */
+  RH_POST_NMS = 4,    /* IoU bitmask + greedy sweep + output gather         */
+  RH_POST_ALL = 7
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RETINAHEAD_H */

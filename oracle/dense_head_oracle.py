@@ -406,7 +406,7 @@ def nms_bruteforce(boxes, scores, iou_threshold, labels=None):
 # --------------------------------------------------------------------------
 def postprocess_image(classification, regression, anchors, height, width,
                       score_thresh=0.05, iou_thresh=0.5, mode="agnostic",
-                      pre_nms_topk=None, max_det=None):
+                      pre_nms_topk=None, max_det=None, boxes=None):
     """One image: (scores f32[K'], labels i64[K'], boxes f32[K',4]).
 
     model.py:320-340: decode, clip, per-anchor max over classes, keep
@@ -414,11 +414,17 @@ def postprocess_image(classification, regression, anchors, height, width,
     outputs in descending score order with the arg-max class as label.
     ``mode='per_class'`` restricts suppression to equal labels;
     ``pre_nms_topk`` keeps the best-scoring candidates (ties: lower anchor
-    index) before NMS; ``max_det`` truncates the kept list.
+    index) before NMS; ``max_det`` truncates the kept list.  ``boxes`` [N,4], when
+    given, replaces the decode + clip step (lets a test feed the device's own decoded
+    boxes, whose exp() may differ from numpy's in the last place, so that keep lists
+    can be compared exactly).
     """
     p = np.asarray(classification, dtype=F32)
-    boxes = clip_boxes(bbox_transform(np.asarray(anchors, F32).reshape(1, -1, 4),
-                                      np.asarray(regression, F32)[None]), height, width)[0]
+    if boxes is None:
+        boxes = clip_boxes(bbox_transform(np.asarray(anchors, F32).reshape(1, -1, 4),
+                                          np.asarray(regression, F32)[None]), height, width)[0]
+    else:
+        boxes = np.asarray(boxes, dtype=F32).reshape(-1, 4)
     score = p.max(axis=1)
     label = p.argmax(axis=1).astype(np.int64)                  # first index on ties
     cand = np.nonzero(score > F32(score_thresh))[0]

@@ -1,0 +1,81 @@
+// Internal helpers shared by the retinahead kernels (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "retinahead.h"
+
+namespace rh {
+
+constexpr int kWave = 64;
+
+// ---- error reporting (thread-local text, C return codes) -------------------
+void set_error(const char* fmt, ...);
+
+#define RH_FAIL(code, ...)            \
+  do {                                \
+    ::rh::set_error(__VA_ARGS__);     \
+    return (code);                    \
+  } while (0)
+
+#define RH_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) RH_FAIL(code, __VA_ARGS__); \
+  } while (0)
+
+// Checks the launch itself (configuration errors); never synchronises.
+#define RH_CHECK_LAUNCH(what)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess)                                                 \
+      RH_FAIL(RH_ELAUNCH, "%s: %s", (what), hipGetErrorString(e__));        \
+  } while (0)
+
+#define RH_CHECK_HIP(expr)                                                 \
+  do {                                                                     \
+    hipError_t e__ = (expr);                                               \
+    if (e__ != hipSuccess)                                                 \
+      RH_FAIL(RH_ELAUNCH, "%s: %s", #expr, hipGetErrorString(e__));         \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carves consecutive 256-byte aligned regions out of a caller-provided workspace.
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += round_up(count * sizeof(T), 256);
+    return r;
+  }
+};
+
+// ---- wave64 reductions ------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Exact x / d for 0 <= x < 2^32 / d, with magic = ceil(2^32 / d)  (d >= 2).
+// Proof: magic*d = 2^32 + e with 0 <= e < d, so x*magic/2^32 = x/d + x*e/(d*2^32),
+// and the extra term is below 1/d whenever x*e < 2^32, which x*d < 2^32 guarantees.
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
+inline uint32_t div_magic(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
+
+}  // namespace rh

@@ -1,0 +1,722 @@
+// Training half of the dense-head path on gfx950: GT compaction, anchor x GT IoU
+// assignment, and the fused focal + smooth-L1 forward/backward stream.
+//
+// Reference behaviour restated here: models/retinanet/losses.py:6-23 (IoU),
+// :48-49 (GT filter), :57 (clamp), :59-61 (max/argmax), :67-94 (targets, focal
+// loss, normaliser), :98-136 (box targets, smooth-L1), :139-141 (batch mean).
+//
+// Everything is HBM-bound float32 streaming; there is no contraction, so no MFMA.
+// The file is compiled with -ffp-contract=off: IoU values feed thresholds and an
+// arg-max whose integer results must equal the reference's bit for bit.
+#include "rh_common.h"
+
+namespace rh {
+
+// One valid ground-truth box, as staged by gt_prepare_kernel (32 bytes).
+struct __attribute__((aligned(16))) GtRec {
+  float x1, y1, x2, y2;
+  float area;
+  int label;   // truncated class, or -1 when outside [0, C)
+  int pad0, pad1;
+};
+
+// Packed per-anchor assignment that the stream kernel consumes.
+//   >= 0 : positive, (gt_index << 16) | label   (label 0xFFFF: class out of range)
+//   -1   : negative (all-zero target row)
+//   -2   : ignored (no loss, no gradient)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kCodeNeg = -1;
+constexpr int kCodeIgn = -2;
+constexpr int kNoLabel = 0xFFFF;
+
+constexpr int kTileRows = 64;      // anchors per stream tile
+constexpr int kThreads = 256;
+constexpr int kGtChunk = 256;      // GT boxes staged in LDS at a time
+constexpr int kGenericBlocks = 64; // blocks per image of the generic row kernel
+
+// ---------------------------------------------------------------------------
+// GT compaction: keeps rows with label != -1 in order (losses.py:48-49), stores
+// their areas (losses.py:7) and truncated labels (.long(), losses.py:79), and
+// zeroes the per-image positive counters.  One wave per image.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict__ ann,
+                                                        GtRec* __restrict__ gt,
+                                                        int* __restrict__ gt_count,
+                                                        int* __restrict__ num_pos,
+                                                        int* __restrict__ status, int M, int C) {
+  const int j = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* a = ann + (size_t)j * M * 5;
+  GtRec* out = gt + (size_t)j * M;
+  int base = 0;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const int m = m0 + lane;
+    float lab = -1.0f;
+    if (m < M) lab = a[m * 5 + 4];
+    const bool valid = (m < M) && (lab != -1.0f);
+    const unsigned long long mask = __ballot(valid);
+    if (valid) {
+      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+      GtRec r;
+      r.x1 = a[m * 5 + 0];
+      r.y1 = a[m * 5 + 1];
+      r.x2 = a[m * 5 + 2];
+      r.y2 = a[m * 5 + 3];
+      r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
+      int l = (int)lab;
+      if (!(lab > -1.0f && lab < (float)C)) {   // also catches NaN
+        l = -1;
+        if (status) atomicOr(status, RH_STATUS_LABEL_RANGE);
+      }
+      r.label = l;
+      r.pad0 = r.pad1 = 0;
+      out[slot] = r;
+    }
+    base += __popcll(mask);
+  }
+  if (lane == 0) {
+    gt_count[j] = base;
+    num_pos[j] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// IoU of one anchor with one GT, float32, operation order of losses.py:9-21.
+// Returns 0 without dividing when the boxes do not overlap (0 / ua == 0 exactly).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float iou_pair(const float4 a, const float area_a, const float4 b,
+                                          const float area_b) {
+  float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  iw = fmaxf(iw, 0.0f);
+  ih = fmaxf(ih, 0.0f);
+  const float inter = iw * ih;
+  if (!(inter > 0.0f)) return 0.0f;
+  float ua = (area_a + area_b) - inter;
+  ua = fmaxf(ua, 1e-8f);
+  return inter / ua;
+}
+
+// ---------------------------------------------------------------------------
+// Assignment: one thread per (image, anchor); the image's GT boxes are staged
+// through LDS in chunks and read as wave-uniform broadcasts.  Max / first arg-max
+// (losses.py:61), thresholds (:70-72), label lookup (:76-79), positive count (:74).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void assign_kernel(
+    const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
+    const int* __restrict__ gt_count, int* __restrict__ code, unsigned char* __restrict__ state,
+    int* __restrict__ argmax, int* __restrict__ label, float* __restrict__ iou_max,
+    int* __restrict__ num_pos, int N, int M, float neg_thresh, float pos_thresh) {
+  __shared__ float4 s_box[kGtChunk];
+  __shared__ float s_area[kGtChunk];
+  __shared__ int s_pos[kThreads / 64];
+
+  const int j = blockIdx.y;
+  const int n = blockIdx.x * kThreads + threadIdx.x;
+  const int cnt = gt_count[j];
+  const GtRec* g = gt + (size_t)j * M;
+
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < N) a = anchors[n];
+  const float area_a = (a.z - a.x) * (a.w - a.y);
+
+  float best = 0.0f;   // every IoU is >= 0, so "first maximum" starts at (0, index 0)
+  int best_idx = 0;
+  for (int c0 = 0; c0 < cnt; c0 += kGtChunk) {
+    const int len = min(kGtChunk, cnt - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += kThreads) {
+      const GtRec r = g[c0 + i];
+      s_box[i] = make_float4(r.x1, r.y1, r.x2, r.y2);
+      s_area[i] = r.area;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < len; ++i) {
+      const float v = iou_pair(a, area_a, s_box[i], s_area[i]);
+      if (v > best) {
+        best = v;
+        best_idx = c0 + i;
+      }
+    }
+  }
+
+  int st, cd, lb = -1;
+  if (cnt == 0) {
+    st = RH_IGNORE;      // losses.py:51-55: the image contributes nothing
+    cd = kCodeIgn;
+  } else if (best >= pos_thresh) {
+    st = RH_POSITIVE;
+    lb = g[best_idx].label;
+    cd = (best_idx << 16) | (lb < 0 ? kNoLabel : lb);
+  } else if (best < neg_thresh) {
+    st = RH_NEGATIVE;
+    cd = kCodeNeg;
+  } else {
+    st = RH_IGNORE;
+    cd = kCodeIgn;
+  }
+  const bool in = n < N;
+  if (in) {
+    const size_t o = (size_t)j * N + n;
+    if (code) code[o] = cd;
+    if (state) state[o] = (unsigned char)st;
+    if (argmax) argmax[o] = best_idx;
+    if (label) label[o] = lb;
+    if (iou_max) iou_max[o] = best;
+  }
+  const unsigned long long pm = __ballot(in && st == RH_POSITIVE);
+  if ((threadIdx.x & 63) == 0) s_pos[threadIdx.x >> 6] = __popcll(pm);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) t += s_pos[w];
+    if (t) atomicAdd(&num_pos[j], t);   // integer add: order-independent
+  }
+}
+
+// Full IoU matrix (losses.py:6-23), one thread per output element.
+__global__ __launch_bounds__(kThreads) void calc_iou_kernel(const float4* __restrict__ a,
+                                                            const float4* __restrict__ b,
+                                                            float* __restrict__ out, long long n,
+                                                            int m) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n * m) return;
+  const long long r = i / m;
+  const int c = (int)(i - r * m);
+  const float4 x = a[r], y = b[c];
+  out[i] = iou_pair(x, (x.z - x.x) * (x.w - x.y), y, (y.z - y.x) * (y.w - y.y));
+}
+
+// ---------------------------------------------------------------------------
+// Element maths shared by the two stream kernels.
+// ---------------------------------------------------------------------------
+struct FocalConst {
+  float alpha;       // weight of target-1 elements; 1-alpha for target-0 (losses.py:81-83)
+  float lo, hi;      // clamp bounds (losses.py:57)
+};
+
+// Loss and d(loss)/dp of one element.  `one`: target is 1; otherwise 0.
+//   target 1: L = a (1-p)^2 (-ln p)      dL/dp =  a [2(1-p) ln p - (1-p)^2 / p]
+//   target 0: L = (1-a) p^2 (-ln(1-p))   dL/dp = -(1-a) [2p ln(1-p) - p^2 / (1-p)]
+// Outside [lo, hi] the clamp blocks the gradient (inclusive bounds pass it).
+__device__ __forceinline__ void focal_elem(const float p, const bool one, const FocalConst k,
+                                           float& loss, float& grad) {
+  const float pc = fminf(fmaxf(p, k.lo), k.hi);
+  const float q = 1.0f - pc;
+  const float u = one ? q : pc;    // focal base
+  const float w = one ? pc : q;    // argument of the log
+  const float a = one ? k.alpha : 1.0f - k.alpha;
+  const float lw = logf(w);
+  const float uu = u * u;
+  loss = (a * uu) * (-lw);
+  float g = a * ((2.0f * u) * lw - uu / w);
+  g = one ? g : -g;
+  grad = (p >= k.lo && p <= k.hi) ? g : 0.0f;
+}
+
+// Smooth-L1 of one regression coordinate of a positive anchor (losses.py:101-133).
+// k = 0..3 selects dx, dy, dw, dh.  Returns the loss; *grad = d loss / d regression.
+__device__ __forceinline__ float smooth_l1_coord(const int k, const float4 a, const GtRec r,
+                                                 const float rv, float* grad) {
+  const float aw = a.z - a.x, ah = a.w - a.y;
+  const float gw = r.x2 - r.x1, gh = r.y2 - r.y1;
+  float t;
+  if (k == 0) {
+    t = ((r.x1 + 0.5f * gw) - (a.x + 0.5f * aw)) / aw;
+  } else if (k == 1) {
+    t = ((r.y1 + 0.5f * gh) - (a.y + 0.5f * ah)) / ah;
+  } else if (k == 2) {
+    t = logf(fmaxf(gw, 1.0f) / aw);
+  } else {
+    t = logf(fmaxf(gh, 1.0f) / ah);
+  }
+  t = t / (k < 2 ? 0.1f : 0.2f);
+  const float diff = t - rv;
+  const float d = fabsf(diff);
+  const bool small = d <= (float)(1.0 / 9.0);
+  const float gmag = small ? 9.0f * d : 1.0f;
+  // d/d rv of |t - rv| is -sign(t - rv); sign(0) = 0
+  *grad = diff > 0.0f ? -gmag : (diff < 0.0f ? gmag : 0.0f);
+  return small ? 4.5f * (d * d) : d - (float)(0.5 / 9.0);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// Tile stream kernel.  The [B*N, C] probability matrix is cut into tiles of 64
+// consecutive rows; a tile starts at a multiple of 64*C floats, so it is 16-byte
+// aligned for every C and is read / written as float4 regardless of row length.
+// Each float4's (row, column) comes from one multiply-high.  Per-row assignment
+// codes sit in LDS.  A tile touches at most two images (host guarantees N >= 64):
+// loss partial sums are kept per (tile, image slot) and written, never atomically
+// added, so the final sums are bitwise reproducible.
+//
+// Requirements checked on the host: 4 <= C < 8192, N >= 64, all pointers 16-byte
+// aligned, B*N < 2^31.
+// ---------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kThreads) void focal_stream_kernel(
+    const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
+    float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
+    const int* __restrict__ code, const int* __restrict__ num_pos, float* __restrict__ partials,
+    int N, int C, int M, int total_rows, int num_tiles, unsigned magic_c, FocalConst fc,
+    float gcls, float greg, float divisor) {
+  __shared__ int s_code[kTileRows];
+  __shared__ float4 s_red[kThreads / 64];
+  const int tid = threadIdx.x;
+
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int row0 = tile * kTileRows;
+    const int rows = min(kTileRows, total_rows - row0);
+    const int j0 = row0 / N;
+    const int split = (j0 + 1) * N - row0;            // first tile-local row of image j0+1
+    const bool two = split < rows;
+    const int np0 = num_pos[j0];
+    const int np1 = two ? num_pos[j0 + 1] : 0;
+    const float norm0 = (float)max(np0, 1), norm1 = (float)max(np1, 1);
+    const float sc0 = gcls / (norm0 * divisor), sc1 = gcls / (norm1 * divisor);
+
+    __syncthreads();   // previous tile's readers of s_code / s_red are done
+    if (tid < kTileRows) s_code[tid] = tid < rows ? code[row0 + tid] : kCodeIgn;
+
+    // ---- regression: 4 lanes per anchor, one coordinate each -----------------
+    float rl0 = 0.f, rl1 = 0.f;
+    {
+      const int r = tid >> 2, k = tid & 3;
+      if (r < rows) {
+        const int grow = row0 + r;
+        const int cd = code[grow];
+        float g = 0.f;
+        if (cd >= 0) {
+          const bool second = r >= split;
+          const int j = second ? j0 + 1 : j0;
+          const float cnt4 = 4.0f * (float)(second ? np1 : np0);
+          const float rv = reg[(size_t)grow * 4 + k];
+          float gr;
+          const float l = smooth_l1_coord(k, anchors[grow - j * N], gt[(size_t)j * M + (cd >> 16)],
+                                          rv, &gr);
+          g = gr * (greg / (cnt4 * divisor));
+          if (second) rl1 = l; else rl0 = l;
+        }
+        __builtin_nontemporal_store(g, &dreg[(size_t)grow * 4 + k]);
+      }
+    }
+    __syncthreads();
+
+    // ---- classification stream ----------------------------------------------
+    const size_t base = (size_t)row0 * C;
+    const v4f* __restrict__ p4 = reinterpret_cast<const v4f*>(prob + base);
+    v4f* __restrict__ d4 = reinterpret_cast<v4f*>(dprob + base);
+    const int elems = rows * C;
+    const int nvec = elems >> 2;
+    float cl0 = 0.f, cl1 = 0.f;
+
+    for (int v0 = tid; v0 < nvec; v0 += kThreads * U) {
+      v4f val[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int v = v0 + u * kThreads;
+        if (v < nvec) val[u] = p4[v];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int v = v0 + u * kThreads;
+        if (v < nvec) {
+          const unsigned x = (unsigned)v << 2;
+          int r = (int)fast_div(x, magic_c);
+          int col = (int)x - r * C;
+          const float in[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+          float out[4];
+          int cd = s_code[r];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (col >= C) {            // C >= 4: at most one row change per float4
+              col -= C;
+              r += 1;
+              cd = s_code[r];
+            }
+            const bool one = cd >= 0 && (cd & 0xFFFF) == col;
+            float l, g;
+            focal_elem(in[e], one, fc, l, g);
+            const bool second = r >= split;
+            const bool live = cd != kCodeIgn;
+            l = live ? l : 0.f;
+            out[e] = live ? g * (second ? sc1 : sc0) : 0.f;
+            cl0 += second ? 0.f : l;
+            cl1 += second ? l : 0.f;
+            col += 1;
+          }
+          v4f o;
+          o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+          __builtin_nontemporal_store(o, &d4[v]);
+        }
+      }
+    }
+    // last tile only: up to 3 trailing elements when B*N*C is not a multiple of 4
+    {
+      const int x = (nvec << 2) + tid;
+      if (x < elems) {
+        const int r = x / C, col = x - r * C;
+        const int cd = s_code[r];
+        const bool one = cd >= 0 && (cd & 0xFFFF) == col;
+        float l, g;
+        focal_elem(prob[base + x], one, fc, l, g);
+        const bool second = r >= split;
+        const bool live = cd != kCodeIgn;
+        dprob[base + x] = live ? g * (second ? sc1 : sc0) : 0.f;
+        l = live ? l : 0.f;
+        cl0 += second ? 0.f : l;
+        cl1 += second ? l : 0.f;
+      }
+    }
+
+    // ---- per-tile partial sums (fixed reduction tree) ------------------------
+    cl0 = wave_sum(cl0);
+    cl1 = wave_sum(cl1);
+    rl0 = wave_sum(rl0);
+    rl1 = wave_sum(rl1);
+    if ((tid & 63) == 0) s_red[tid >> 6] = make_float4(cl0, cl1, rl0, rl1);
+    __syncthreads();
+    if (tid == 0) {
+      const float4 a = s_red[0], b = s_red[1], c = s_red[2], d = s_red[3];
+      reinterpret_cast<float4*>(partials)[tile] =
+          make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y),
+                      (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic row kernel: any N, C and alignment.  Grid (kGenericBlocks, B); one wave
+// per anchor row at a time, scalar loads.  Used for shapes the tile kernel does
+// not take (C < 4, C >= 8192, N < 64, unaligned tensors).
+// partials layout: [B][kGenericBlocks][2] (classification, regression).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void focal_rows_kernel(
+    const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
+    float* __restrict__ dreg, const float* __restrict__ anchors, const GtRec* __restrict__ gt,
+    const int* __restrict__ code, const int* __restrict__ num_pos, float* __restrict__ partials,
+    int N, int C, int M, FocalConst fc, float gcls, float greg, float divisor) {
+  __shared__ float s_red[4];
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int np = num_pos[j];
+  const float sc = gcls / ((float)max(np, 1) * divisor);
+  const float rsc = greg / ((4.0f * (float)np) * divisor);
+  float cl = 0.f, rl = 0.f;
+  for (int n = blockIdx.x * (kThreads / 64) + wave; n < N; n += gridDim.x * (kThreads / 64)) {
+    const size_t row = (size_t)j * N + n;
+    const int cd = code[row];
+    const bool live = cd != kCodeIgn;
+    const float* p = prob + row * C;
+    float* d = dprob + row * C;
+    for (int c = lane; c < C; c += 64) {
+      float l, g;
+      focal_elem(p[c], cd >= 0 && (cd & 0xFFFF) == c, fc, l, g);
+      d[c] = live ? g * sc : 0.f;
+      cl += live ? l : 0.f;
+    }
+    if (lane < 4) {
+      float g = 0.f;
+      if (cd >= 0) {
+        const float4 a = make_float4(anchors[(size_t)n * 4], anchors[(size_t)n * 4 + 1],
+                                     anchors[(size_t)n * 4 + 2], anchors[(size_t)n * 4 + 3]);
+        float gr;
+        rl += smooth_l1_coord(lane, a, gt[(size_t)j * M + (cd >> 16)], reg[row * 4 + lane], &gr);
+        g = gr * rsc;
+      }
+      dreg[row * 4 + lane] = g;
+    }
+  }
+  const float t0 = block_sum_256(cl, s_red);
+  const float t1 = block_sum_256(rl, s_red);
+  if (threadIdx.x == 0) {
+    float* o = partials + ((size_t)j * gridDim.x + blockIdx.x) * 2;
+    o[0] = t0;
+    o[1] = t1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Final reductions (fixed order, double accumulation).
+// finalize_images: one block per image; sums the image's partials, applies the
+// normalisers of losses.py:94 and :134.  tile_mode: partials are the tile
+// kernel's [tile][4] records, else the generic kernel's [B][blocks][2].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void finalize_images_kernel(
+    const float* __restrict__ partials, const int* __restrict__ num_pos,
+    const int* __restrict__ gt_count, float* __restrict__ per_image, int* __restrict__ num_pos_out,
+    int B, int N, int tile_mode, int generic_blocks) {
+  __shared__ double s_c[kThreads / 64], s_r[kThreads / 64];
+  const int j = blockIdx.x;
+  double c = 0.0, r = 0.0;
+  if (tile_mode) {
+    const long long first = (long long)j * N, last = first + N - 1;
+    const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
+    for (int t = t_lo + threadIdx.x; t <= t_hi; t += kThreads) {
+      const int slot = j - (int)(((long long)t * kTileRows) / N);   // 0 or 1
+      const float4 q = reinterpret_cast<const float4*>(partials)[t];
+      c += slot ? q.y : q.x;
+      r += slot ? q.w : q.z;
+    }
+  } else {
+    for (int t = threadIdx.x; t < generic_blocks; t += kThreads) {
+      c += partials[((size_t)j * generic_blocks + t) * 2];
+      r += partials[((size_t)j * generic_blocks + t) * 2 + 1];
+    }
+  }
+  c = wave_sum(c);
+  r = wave_sum(r);
+  if ((threadIdx.x & 63) == 0) {
+    s_c[threadIdx.x >> 6] = c;
+    s_r[threadIdx.x >> 6] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double cs = 0.0, rs = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+      cs += s_c[w];
+      rs += s_r[w];
+    }
+    const int np = num_pos[j];
+    const bool empty = gt_count[j] == 0;
+    per_image[j] = empty ? 0.f : (float)cs / (float)max(np, 1);
+    per_image[B + j] = (empty || np == 0) ? 0.f : (float)rs / (4.0f * (float)np);
+    if (num_pos_out) num_pos_out[j] = np;
+  }
+}
+
+// Batch means (losses.py:139-141): one wave, lane-strided then a fixed butterfly.
+__global__ __launch_bounds__(64) void finalize_batch_kernel(const float* __restrict__ per_image,
+                                                            float* __restrict__ losses, int B,
+                                                            float divisor) {
+  double c = 0.0, r = 0.0;
+  for (int j = threadIdx.x; j < B; j += 64) {
+    c += per_image[j];
+    r += per_image[B + j];
+  }
+  c = wave_sum(c);
+  r = wave_sum(r);
+  if (threadIdx.x == 0) {
+    losses[0] = (float)(c / (double)divisor);
+    losses[1] = (float)(r / (double)divisor);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void scale_inplace_kernel(float* __restrict__ x,
+                                                                 long long count,
+                                                                 const float* __restrict__ scale,
+                                                                 float assumed) {
+  const float s = *scale;
+  if (s == assumed) return;          // uniform: the whole grid leaves without traffic
+  const float f = s / assumed;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride)
+    x[i] *= f;
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+struct LossWorkspace {
+  GtRec* gt;
+  int* gt_count;
+  int* num_pos;
+  int* code;
+  float* partials;
+  float* per_image;
+  size_t bytes;
+};
+
+static bool tile_path_ok(long long n, int c) { return n >= kTileRows && c >= 4 && c < 8192; }
+
+static long long partial_floats(int batch, long long n, int c) {
+  const long long tiles = ((long long)batch * n + kTileRows - 1) / kTileRows;
+  const long long a = tiles * 4, b = (long long)batch * kGenericBlocks * 2;
+  return a > b ? a : b;
+}
+
+static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) {
+  Carver cv(ws);
+  LossWorkspace w;
+  w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
+  w.gt_count = cv.take<int>(batch);
+  w.num_pos = cv.take<int>(batch);
+  w.code = cv.take<int>((size_t)batch * n);
+  w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
+  w.per_image = cv.take<float>((size_t)2 * batch);
+  w.bytes = cv.off;
+  return w;
+}
+
+static int check_assign_shapes(int batch, long long n, int m, int c) {
+  RH_REQUIRE(batch >= 1 && n >= 1 && m >= 0 && c >= 1, RH_ESHAPE,
+             "bad shape: batch=%d n=%lld m=%d classes=%d", batch, n, m, c);
+  RH_REQUIRE((long long)batch * n < (1ll << 31), RH_ESHAPE, "batch*n=%lld does not fit 31 bits",
+             (long long)batch * n);
+  RH_REQUIRE(m < 32768, RH_ESHAPE, "m=%d: at most 32767 annotation rows per image", m);
+  RH_REQUIRE(c < 65535, RH_ESHAPE, "classes=%d: at most 65534", c);
+  RH_REQUIRE(batch <= 65535, RH_ESHAPE, "batch=%d: at most 65535 images per call", batch);
+  return RH_OK;
+}
+
+static int launch_assign(const float* anchors, const float* annotations, int batch, long long n,
+                         int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
+                         unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(gt_prepare_kernel, dim3(batch), dim3(64), 0, s, annotations, w.gt, w.gt_count,
+                     w.num_pos, status, m, c);
+  RH_CHECK_LAUNCH("gt_prepare_kernel");
+  dim3 grid((unsigned)((n + kThreads - 1) / kThreads), (unsigned)batch);
+  hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
+                     reinterpret_cast<const float4*>(anchors), w.gt, w.gt_count, code, state, argmax,
+                     label, iou_max, w.num_pos, (int)n, m, neg_t, pos_t);
+  RH_CHECK_LAUNCH("assign_kernel");
+  return RH_OK;
+}
+
+}  // namespace rh
+
+using namespace rh;
+
+extern "C" {
+
+int rh_calc_iou_f32(const float* a, int64_t n, const float* b, int64_t m, float* out,
+                    rh_stream_t stream) {
+  RH_REQUIRE(n >= 0 && m >= 0 && m < (1ll << 31), RH_ESHAPE, "bad shape n=%lld m=%lld",
+             (long long)n, (long long)m);
+  if (n == 0 || m == 0) return RH_OK;
+  RH_REQUIRE(a && b && out, RH_EINVAL, "null pointer");
+  RH_REQUIRE(aligned16(a) && aligned16(b), RH_EALIGN, "box arrays must be 16-byte aligned");
+  const long long total = (long long)n * m;
+  RH_REQUIRE((total + kThreads - 1) / kThreads < (1ll << 31), RH_ESHAPE, "n*m too large");
+  hipLaunchKernelGGL(calc_iou_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                     reinterpret_cast<const float4*>(b), out, (long long)n, (int)m);
+  RH_CHECK_LAUNCH("calc_iou_kernel");
+  return RH_OK;
+}
+
+size_t rh_assign_workspace_bytes(int32_t batch, int64_t n, int32_t m) {
+  if (batch < 1 || n < 1 || m < 0) return 0;
+  Carver cv(nullptr);
+  cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
+  cv.take<int>(batch);
+  cv.take<int>(batch);
+  return cv.off;
+}
+
+int rh_assign(const float* anchors, const float* annotations, int32_t batch, int64_t n, int32_t m,
+              int32_t num_classes, float neg_thresh, float pos_thresh, uint8_t* state,
+              int32_t* argmax, int32_t* label, float* iou_max, int32_t* num_pos, int32_t* status,
+              void* workspace, size_t workspace_bytes, rh_stream_t stream) {
+  if (int e = check_assign_shapes(batch, n, m, num_classes)) return e;
+  RH_REQUIRE(anchors && (annotations || m == 0) && num_pos, RH_EINVAL, "null pointer");
+  RH_REQUIRE(aligned16(anchors), RH_EALIGN, "anchors must be 16-byte aligned");
+  RH_REQUIRE(workspace && workspace_bytes >= rh_assign_workspace_bytes(batch, n, m), RH_EWORKSPACE,
+             "workspace too small: need %zu bytes", rh_assign_workspace_bytes(batch, n, m));
+  RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
+  Carver cv(workspace);
+  LossWorkspace w{};
+  w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
+  w.gt_count = cv.take<int>(batch);
+  cv.take<int>(batch);
+  w.num_pos = num_pos;
+  return launch_assign(anchors, annotations, batch, n, m, num_classes, neg_thresh, pos_thresh, w,
+                       nullptr, state, argmax, label, iou_max, status, (hipStream_t)stream);
+}
+
+size_t rh_focal_loss_workspace_bytes(int32_t batch, int64_t n, int32_t num_classes, int32_t m) {
+  if (batch < 1 || n < 1 || num_classes < 1 || m < 0) return 0;
+  return carve_loss(nullptr, batch, n, num_classes, m).bytes;
+}
+
+int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions,
+                          const float* anchors, const float* annotations, int32_t batch, int64_t n,
+                          int32_t num_classes, int32_t m, const rh_focal_params* params,
+                          float* d_classifications, float* d_regressions, float* losses,
+                          float* per_image, int32_t* num_pos, int32_t* status, void* workspace,
+                          size_t workspace_bytes, int32_t stages, rh_stream_t stream) {
+  if (int e = check_assign_shapes(batch, n, m, num_classes)) return e;
+  RH_REQUIRE(classifications && regressions && anchors && (annotations || m == 0) &&
+                 d_classifications && d_regressions && losses && params,
+             RH_EINVAL, "null pointer");
+  RH_REQUIRE(aligned16(anchors), RH_EALIGN, "anchors must be 16-byte aligned");
+  const size_t need = rh_focal_loss_workspace_bytes(batch, n, num_classes, m);
+  RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
+             "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
+  RH_REQUIRE(params->batch_divisor >= 0, RH_EINVAL, "batch_divisor < 0");
+  RH_REQUIRE((stages & ~RH_STAGE_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
+
+  hipStream_t s = (hipStream_t)stream;
+  const LossWorkspace w = carve_loss(workspace, batch, n, num_classes, m);
+  const float divisor = (float)(params->batch_divisor > 0 ? params->batch_divisor : batch);
+  const FocalConst fc{params->alpha, 1e-4f, (float)(1.0 - 1e-4)};
+  const bool tile = tile_path_ok(n, num_classes) && aligned16(classifications) &&
+                    aligned16(d_classifications);
+  const int total_rows = (int)((long long)batch * n);
+  const int num_tiles = (total_rows + kTileRows - 1) / kTileRows;
+
+  if (stages & RH_STAGE_ASSIGN) {
+    if (int e = launch_assign(anchors, annotations, batch, n, m, num_classes, params->neg_thresh,
+                              params->pos_thresh, w, w.code, nullptr, nullptr, nullptr, nullptr,
+                              status, s))
+      return e;
+  }
+  if (stages & RH_STAGE_STREAM) {
+    if (tile) {
+      const int grid = num_tiles < 256 * 8 ? num_tiles : 256 * 8;
+      hipLaunchKernelGGL(focal_stream_kernel<4>, dim3(grid), dim3(kThreads), 0, s, classifications,
+                         d_classifications, regressions, d_regressions,
+                         reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.num_pos,
+                         w.partials, (int)n, num_classes, m, total_rows, num_tiles,
+                         div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
+                         divisor);
+      RH_CHECK_LAUNCH("focal_stream_kernel");
+    } else {
+      hipLaunchKernelGGL(focal_rows_kernel, dim3(kGenericBlocks, batch), dim3(kThreads), 0, s,
+                         classifications, d_classifications, regressions, d_regressions, anchors,
+                         w.gt, w.code, w.num_pos, w.partials, (int)n, num_classes, m, fc,
+                         params->grad_cls, params->grad_reg, divisor);
+      RH_CHECK_LAUNCH("focal_rows_kernel");
+    }
+  }
+  if (stages & RH_STAGE_FINALIZE) {
+    float* pi = per_image ? per_image : w.per_image;
+    hipLaunchKernelGGL(finalize_images_kernel, dim3(batch), dim3(kThreads), 0, s, w.partials,
+                       w.num_pos, w.gt_count, pi, num_pos, batch, (int)n, tile ? 1 : 0,
+                       kGenericBlocks);
+    RH_CHECK_LAUNCH("finalize_images_kernel");
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(1), dim3(64), 0, s, pi, losses, batch, divisor);
+    RH_CHECK_LAUNCH("finalize_batch_kernel");
+  }
+  return RH_OK;
+}
+
+int rh_scale_inplace_f32(float* x, int64_t count, const float* scale_dev, float assumed,
+                         rh_stream_t stream) {
+  RH_REQUIRE(count >= 0, RH_ESHAPE, "count < 0");
+  if (count == 0) return RH_OK;
+  RH_REQUIRE(x && scale_dev, RH_EINVAL, "null pointer");
+  RH_REQUIRE(assumed != 0.0f, RH_EINVAL, "assumed scale must be non-zero");
+  long long blocks = (count + kThreads - 1) / kThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, (long long)count, scale_dev, assumed);
+  RH_CHECK_LAUNCH("scale_inplace_kernel");
+  return RH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+"""Data-parallel use of the dense-head loss: one process per GPU, images sharded.
+
+Every quantity of the loss is per image (models/retinanet/losses.py:43-136); the
+only cross-image step is the batch mean (losses.py:139-140).  So a rank runs the
+fused kernels on its own images with ``batch_divisor`` = global batch size, which
+already scales its losses and gradients by 1/B_global, and ONE all-reduce (sum) of
+a 2-float vector over RCCL/xGMI yields the global losses.  Gradients with respect
+to the predictions need no exchange.  The reference's own multi-GPU mechanism is
+nn.DataParallel (train.py:137).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist_
+
+
+def shard_bounds(global_batch, rank, world_size):
+    """Contiguous image range [lo, hi) of ``rank``; the first ranks take the remainder."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank outside world")
+    base, rem = divmod(int(global_batch), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_reduce_losses(local_losses, group=None):
+    """Sums the [2] loss vectors of all ranks.  The value is the global loss, the
+    gradient is that of the local share (each rank back-propagates its own images)."""
+    if not (dist_.is_available() and dist_.is_initialized()) or dist_.get_world_size(group) == 1:
+        return local_losses
+    total = local_losses.detach().clone()
+    dist_.all_reduce(total, op=dist_.ReduceOp.SUM, group=group)
+    return local_losses + (total - local_losses.detach())
+
+
+class DataParallelFocalLoss(torch.nn.Module):
+    """Wraps a loss callable with the FocalLoss signature for sharded batches.
+
+    ``loss_fn(classifications, regressions, anchors, annotations)`` must return the
+    two-entry dict of losses computed with ``batch_divisor = global_batch`` (for
+    ``retinahead.FocalLoss`` pass ``batch_divisor`` at construction).
+    """
+
+    def __init__(self, loss_fn, group=None):
+        super().__init__()
+        self.loss_fn = loss_fn
+        self.group = group
+
+    def forward(self, classifications, regressions, anchors, annotations):
+        out = self.loss_fn(classifications, regressions, anchors, annotations)
+        vec = torch.cat([out["classification_loss"].reshape(1), out["regression_loss"].reshape(1)])
+        vec = all_reduce_losses(vec, self.group)
+        return {"classification_loss": vec[0:1], "regression_loss": vec[1:2]}

@@ -1,0 +1,334 @@
+"""Tensor-level wrappers over the C ABI: argument checks, workspace, stream plumbing.
+
+PyTorch is used for device memory, the current stream and autograd bookkeeping
+only; every computation below is a libretinahead.so kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import RetinaHeadError
+
+_workspaces = {}
+
+
+def _dev_check(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RetinaHeadError("retinahead operators need tensors on a HIP device "
+                                  "(there is no CPU fallback)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RetinaHeadError(f"tensors on different devices: {dev} and {t.device}")
+    return dev
+
+
+def _f32c(t):
+    """float32, contiguous, 16-byte aligned storage offset."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def workspace(dev, nbytes, tag="default"):
+    """A cached byte buffer per (device, stream, tag); grows, never shrinks."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        _workspaces[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------- anchors
+def make_anchor_cfg(pyramid_levels=None, strides=None, sizes=None, ratios=None, scales=None):
+    cfg = _lib.AnchorCfg()
+    _lib.load().rh_anchor_cfg_default(C.byref(cfg))
+    if pyramid_levels is not None:
+        levels = [int(l) for l in pyramid_levels]
+        if not 1 <= len(levels) <= _lib.MAX_LEVELS:
+            raise RetinaHeadError(f"1..{_lib.MAX_LEVELS} pyramid levels supported")
+        cfg.num_levels = len(levels)
+        for i, l in enumerate(levels):
+            cfg.levels[i] = l
+            cfg.strides[i] = float(2 ** l)
+            cfg.sizes[i] = float(2 ** (l + 2))
+    if strides is not None:
+        for i, s in enumerate(strides):
+            cfg.strides[i] = float(s)
+    if sizes is not None:
+        for i, s in enumerate(sizes):
+            cfg.sizes[i] = float(s)
+    if ratios is not None:
+        r = [float(x) for x in ratios]
+        if not 1 <= len(r) <= _lib.MAX_RATIOS:
+            raise RetinaHeadError(f"1..{_lib.MAX_RATIOS} ratios supported")
+        cfg.num_ratios = len(r)
+        for i, x in enumerate(r):
+            cfg.ratios[i] = x
+    if scales is not None:
+        s = [float(x) for x in scales]
+        if not 1 <= len(s) <= _lib.MAX_SCALES:
+            raise RetinaHeadError(f"1..{_lib.MAX_SCALES} scales supported")
+        cfg.num_scales = len(s)
+        for i, x in enumerate(s):
+            cfg.scales[i] = x
+    return cfg
+
+
+def anchor_count(cfg, height, width):
+    n = _lib.load().rh_anchor_count(C.byref(cfg), int(height), int(width))
+    if n < 0:
+        _lib.check(int(n), "rh_anchor_count")
+    return int(n)
+
+
+def anchors(cfg, height, width, device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RetinaHeadError("anchors are generated on a HIP device (no CPU fallback)")
+    n = anchor_count(cfg, height, width)
+    out = torch.empty((1, n, 4), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().rh_anchors_f32(C.byref(cfg), int(height), int(width), _p(out), n,
+                                              _stream(device)), "rh_anchors_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- IoU / assignment
+def calc_iou(a, b):
+    dev = _dev_check(a, b)
+    a, b = _f32c(a), _f32c(b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 4 or b.shape[1] != 4:
+        raise RetinaHeadError("calc_iou expects a[N,4], b[M,4]")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_calc_iou_f32(_p(a), a.shape[0], _p(b), b.shape[0], _p(out),
+                                               _stream(dev)), "rh_calc_iou_f32")
+    return out
+
+
+def _anchors2d(anchors_t):
+    if anchors_t.dim() == 3:
+        if anchors_t.shape[0] != 1:
+            raise RetinaHeadError("anchors must be [1,N,4] or [N,4]")
+        anchors_t = anchors_t[0]
+    if anchors_t.dim() != 2 or anchors_t.shape[1] != 4:
+        raise RetinaHeadError("anchors must be [1,N,4] or [N,4]")
+    return _f32c(anchors_t)
+
+
+def assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5):
+    """Per-anchor assignment for a batch; returns a dict of device tensors."""
+    dev = _dev_check(anchors_t, annotations)
+    anc = _anchors2d(anchors_t)
+    ann = _f32c(annotations)
+    if ann.dim() != 3 or ann.shape[2] != 5:
+        raise RetinaHeadError("annotations must be [B,M,5]")
+    bsz, m, n = ann.shape[0], ann.shape[1], anc.shape[0]
+    lib = _lib.load()
+    state = torch.empty((bsz, n), dtype=torch.uint8, device=dev)
+    argmax = torch.empty((bsz, n), dtype=torch.int32, device=dev)
+    label = torch.empty((bsz, n), dtype=torch.int32, device=dev)
+    iou_max = torch.empty((bsz, n), dtype=torch.float32, device=dev)
+    num_pos = torch.empty((bsz,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    need = lib.rh_assign_workspace_bytes(bsz, n, m)
+    ws = workspace(dev, need, "assign")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rh_assign(_p(anc), _p(ann), bsz, n, m, int(num_classes), float(neg_thresh),
+                                 float(pos_thresh), _p(state), _p(argmax), _p(label), _p(iou_max),
+                                 _p(num_pos), _p(status), _p(ws), ws.numel(), _stream(dev)),
+                   "rh_assign")
+    return dict(state=state, argmax=argmax, label=label, iou_max=iou_max, num_pos=num_pos,
+                status=status)
+
+
+# --------------------------------------------------------------------------- fused loss
+def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alpha=0.25,
+                       neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
+                       batch_divisor=0, stages=_lib.STAGE_ALL, out=None):
+    """Runs the fused loss kernels.  Returns a dict of device tensors:
+    losses [2], per_image [2,B], num_pos [B], status [1], d_classifications, d_regressions.
+    ``out`` may carry buffers from an earlier call (used when stages are run one at a time).
+    """
+    dev = _dev_check(classifications, regressions, anchors_t, annotations)
+    cls, reg = _f32c(classifications), _f32c(regressions)
+    anc, ann = _anchors2d(anchors_t), _f32c(annotations)
+    if cls.dim() != 3 or reg.dim() != 3 or reg.shape[2] != 4 or cls.shape[:2] != reg.shape[:2]:
+        raise RetinaHeadError("expected classifications [B,N,C] and regressions [B,N,4]")
+    if ann.dim() != 3 or ann.shape[2] != 5 or ann.shape[0] != cls.shape[0]:
+        raise RetinaHeadError("annotations must be [B,M,5]")
+    if anc.shape[0] != cls.shape[1]:
+        raise RetinaHeadError(f"{anc.shape[0]} anchors but {cls.shape[1]} prediction rows")
+    bsz, n, c = cls.shape
+    m = ann.shape[1]
+    lib = _lib.load()
+    if out is None:
+        out = dict(
+            losses=torch.empty((2,), dtype=torch.float32, device=dev),
+            per_image=torch.empty((2, bsz), dtype=torch.float32, device=dev),
+            num_pos=torch.empty((bsz,), dtype=torch.int32, device=dev),
+            status=torch.zeros((1,), dtype=torch.int32, device=dev),
+            d_classifications=torch.empty_like(cls),
+            d_regressions=torch.empty_like(reg),
+        )
+    params = _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
+                              float(grad_reg), int(batch_divisor))
+    need = lib.rh_focal_loss_workspace_bytes(bsz, n, c, m)
+    ws = workspace(dev, need, "focal")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rh_focal_loss_fwd_bwd(
+            _p(cls), _p(reg), _p(anc), _p(ann), bsz, n, c, m, C.byref(params),
+            _p(out["d_classifications"]), _p(out["d_regressions"]), _p(out["losses"]),
+            _p(out["per_image"]), _p(out["num_pos"]), _p(out["status"]), _p(ws), ws.numel(),
+            int(stages), _stream(dev)), "rh_focal_loss_fwd_bwd")
+    return out
+
+
+def scale_inplace(x, scale, assumed=1.0):
+    """x *= scale / assumed on the device, skipped (no traffic) when scale == assumed."""
+    dev = _dev_check(x, scale)
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise RetinaHeadError("scale_inplace needs a contiguous float32 tensor")
+    s = _f32c(scale.reshape(-1)[:1])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_scale_inplace_f32(_p(x), x.numel(), _p(s), float(assumed),
+                                                    _stream(dev)), "rh_scale_inplace_f32")
+    return x
+
+
+def generic_focal_fwd_bwd(inputs, targets, alpha=0.25, gamma=2.0, logits=True, reduce=True):
+    """Returns (loss, grad): loss is [1]-less scalar tensor when reduce else inputs-shaped."""
+    dev = _dev_check(inputs, targets)
+    x, t = _f32c(inputs), _f32c(targets)
+    if x.shape != t.shape:
+        raise RetinaHeadError("inputs and targets must have the same shape")
+    lib = _lib.load()
+    grad = torch.empty_like(x)
+    loss_elem = None if reduce else torch.empty_like(x)
+    loss_mean = torch.empty((), dtype=torch.float32, device=dev)
+    ws = workspace(dev, lib.rh_generic_focal_workspace_bytes(x.numel()), "generic")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rh_generic_focal_fwd_bwd(_p(x), _p(t), x.numel(), float(alpha), float(gamma),
+                                                int(bool(logits)), int(bool(reduce)), _p(loss_elem),
+                                                _p(loss_mean), _p(grad), _p(ws), ws.numel(),
+                                                _stream(dev)), "rh_generic_focal_fwd_bwd")
+    return (loss_mean if reduce else loss_elem), grad
+
+
+# --------------------------------------------------------------------------- decode / clip
+def bbox_transform(boxes, deltas, mean=None, std=None):
+    dev = _dev_check(boxes, deltas)
+    anc, d = _anchors2d(boxes), _f32c(deltas)
+    if d.dim() != 3 or d.shape[2] != 4 or d.shape[1] != anc.shape[0]:
+        raise RetinaHeadError("expected boxes [1,N,4] and deltas [B,N,4]")
+    out = torch.empty_like(d)
+    arr = lambda v: None if v is None else (C.c_float * 4)(*[float(x) for x in v])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_bbox_transform_f32(_p(anc), _p(d), d.shape[0], d.shape[1], arr(mean),
+                                                     arr(std), _p(out), _stream(dev)),
+                   "rh_bbox_transform_f32")
+    return out
+
+
+def clip_boxes_(boxes, height, width):
+    """In place (utils.py:136-140)."""
+    dev = _dev_check(boxes)
+    if boxes.dtype != torch.float32 or not boxes.is_contiguous() or boxes.shape[-1] != 4 \
+            or boxes.data_ptr() % 16:
+        raise RetinaHeadError("clip_boxes_ needs a contiguous, aligned float32 [...,4] tensor")
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_clip_boxes_f32(_p(boxes), boxes.numel() // 4, float(width),
+                                                 float(height), _stream(dev)), "rh_clip_boxes_f32")
+    return boxes
+
+
+# --------------------------------------------------------------------------- NMS / post-processing
+def nms(boxes, scores, iou_threshold, labels: Optional[torch.Tensor] = None):
+    """Kept indices (int64, descending score).  One host read of the kept count."""
+    dev = _dev_check(boxes, scores, labels)
+    b = _f32c(boxes)
+    s = _f32c(scores.reshape(-1))
+    if b.dim() != 2 or b.shape[1] != 4 or s.shape[0] != b.shape[0]:
+        raise RetinaHeadError("nms expects boxes [K,4] and scores [K] or [K,1]")
+    k = b.shape[0]
+    if k == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=dev)
+    lab = None
+    if labels is not None:
+        lab = labels.reshape(-1).to(torch.int32).contiguous()
+    lib = _lib.load()
+    keep = torch.empty((k,), dtype=torch.int64, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    need = lib.rh_nms_workspace_bytes(k)
+    if need == 0:
+        raise RetinaHeadError(f"nms: k={k} out of range")
+    ws = workspace(dev, need, "nms")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rh_nms(_p(b), _p(s), _p(lab), k, float(iou_threshold), _p(keep), _p(count),
+                              _p(ws), ws.numel(), _stream(dev)), "rh_nms")
+    return keep[: int(count.item())]
+
+
+def postprocess_raw(classifications, regressions, anchors_t, height, width, score_thresh=0.05,
+                    iou_thresh=0.5, per_class=False, pre_nms_topk=0, max_det=0, cand_cap=4096,
+                    stages=_lib.POST_ALL, out=None):
+    """One pass of the batched post-processing kernels; no host synchronisation.
+
+    Returns dict(scores [B,cap], labels [B,cap] i64, boxes [B,cap,4], counts [3,B] i32) where
+    counts rows are (kept, candidates over threshold, candidates dropped for lack of room).
+    """
+    dev = _dev_check(classifications, regressions, anchors_t)
+    cls, reg, anc = _f32c(classifications), _f32c(regressions), _anchors2d(anchors_t)
+    if cls.dim() != 3 or reg.dim() != 3 or reg.shape[2] != 4 or cls.shape[:2] != reg.shape[:2]:
+        raise RetinaHeadError("expected classifications [B,N,C] and regressions [B,N,4]")
+    if anc.shape[0] != cls.shape[1]:
+        raise RetinaHeadError(f"{anc.shape[0]} anchors but {cls.shape[1]} prediction rows")
+    bsz, n, c = cls.shape
+    cand_cap = max(1, min(int(cand_cap), n))
+    topk = int(pre_nms_topk or 0)
+    max_det = int(max_det or 0)
+    box_cap = min(cand_cap, topk) if topk > 0 else cand_cap
+    out_cap = max_det if max_det > 0 else box_cap
+    params = _lib.PostParams(float(height), float(width), float(score_thresh), float(iou_thresh),
+                             int(bool(per_class)), topk, max_det, cand_cap)
+    lib = _lib.load()
+    if out is None:
+        out = dict(
+            scores=torch.empty((bsz, out_cap), dtype=torch.float32, device=dev),
+            labels=torch.empty((bsz, out_cap), dtype=torch.int64, device=dev),
+            boxes=torch.empty((bsz, out_cap, 4), dtype=torch.float32, device=dev),
+            counts=torch.zeros((3, bsz), dtype=torch.int32, device=dev),
+        )
+    need = lib.rh_postprocess_workspace_bytes(bsz, n, c, C.byref(params))
+    if need == 0:
+        raise RetinaHeadError("postprocess: " + _lib.last_error())
+    ws = workspace(dev, need, "post")
+    cnt = out["counts"]
+    with torch.cuda.device(dev):
+        _lib.check(lib.rh_postprocess(
+            _p(cls), _p(reg), _p(anc), bsz, n, c, C.byref(params), _p(out["scores"]),
+            _p(out["labels"]), _p(out["boxes"]), _p(cnt[0]), _p(cnt[1]), _p(cnt[2]), _p(ws),
+            ws.numel(), int(stages), _stream(dev)), "rh_postprocess")
+    return out

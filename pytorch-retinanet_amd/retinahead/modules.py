@@ -1,0 +1,257 @@
+"""Drop-in operators with the reference's call signatures.
+
+Each class/function names the reference symbol it replaces; replacing the four
+attribute assignments at models/retinanet/model.py:231-237 and the ``nms``
+import at model.py:8 with these is the whole integration.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import functional as F
+from ._lib import RetinaHeadError
+
+
+def calc_iou(a, b):
+    """[N,M] IoU of a[N,4] and b[M,4]; replaces calc_iou (models/retinanet/losses.py:6-23)."""
+    return F.calc_iou(a, b)
+
+
+class _DenseHeadLossFn(torch.autograd.Function):
+    """Forward launches the fused forward+backward kernels and keeps the gradients;
+    backward applies the upstream gradients to them in place (no host read)."""
+
+    @staticmethod
+    def forward(ctx, classifications, regressions, anchors, annotations, cfg):
+        out = F.focal_loss_fwd_bwd(
+            classifications, regressions, anchors, annotations, alpha=cfg["alpha"],
+            neg_thresh=cfg["neg_thresh"], pos_thresh=cfg["pos_thresh"],
+            grad_cls=cfg["expected_grad"], grad_reg=cfg["expected_grad"],
+            batch_divisor=cfg["batch_divisor"])
+        ctx.d_cls = out["d_classifications"]
+        ctx.d_reg = out["d_regressions"]
+        ctx.expected = cfg["expected_grad"]
+        ctx.in_dtypes = (classifications.dtype, regressions.dtype)
+        cfg["last"] = out
+        losses = out["losses"]
+        return losses[0:1].clone(), losses[1:2].clone()
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        if ctx.d_cls is None:
+            raise RetinaHeadError("the fused loss keeps one set of gradients: backward() can run "
+                                  "once per forward()")
+        d_cls, d_reg = ctx.d_cls, ctx.d_reg
+        ctx.d_cls = ctx.d_reg = None
+        need = ctx.needs_input_grad
+        out_cls = out_reg = None
+        if need[0]:
+            if g_cls is None:
+                out_cls = torch.zeros_like(d_cls)
+            else:
+                out_cls = F.scale_inplace(d_cls, g_cls, ctx.expected)
+            out_cls = out_cls.to(ctx.in_dtypes[0])
+        if need[1]:
+            if g_reg is None:
+                out_reg = torch.zeros_like(d_reg)
+            else:
+                out_reg = F.scale_inplace(d_reg, g_reg, ctx.expected)
+            out_reg = out_reg.to(ctx.in_dtypes[1])
+        return out_cls, out_reg, None, None, None
+
+
+class FocalLoss(nn.Module):
+    """Replaces FocalLoss (models/retinanet/losses.py:26-141).
+
+    ``forward(classifications[B,N,C], regressions[B,N,4], anchors[1,N,4],
+    annotations[B,M,5])`` returns ``{'classification_loss': Tensor[1],
+    'regression_loss': Tensor[1]}``, differentiable with respect to the first two
+    arguments.  The reference's constants are keyword arguments with the
+    reference values as defaults (alpha .25, IoU thresholds .4/.5; gamma is 2).
+
+    expected_grad: the upstream gradient both losses are expected to receive in
+        ``backward`` (1 for ``sum(losses).backward()``, ``1/iterations`` for the
+        accumulation loop of train.py:185-190).  The stored gradients are
+        pre-multiplied by it, so a matching backward touches no memory; any other
+        value is applied by one in-place scaling pass.
+    batch_divisor: number of images the batch mean runs over (0: this batch).
+        A data-parallel shard passes the global batch size.
+    check_labels: read the device status word after the call (one host
+        synchronisation) and raise IndexError for a label outside [0, C), as
+        losses.py:79 does.
+    """
+
+    def __init__(self, alpha=0.25, neg_thresh=0.4, pos_thresh=0.5, expected_grad=1.0,
+                 batch_divisor=0, check_labels=False):
+        super().__init__()
+        self.cfg = dict(alpha=float(alpha), neg_thresh=float(neg_thresh),
+                        pos_thresh=float(pos_thresh), expected_grad=float(expected_grad),
+                        batch_divisor=int(batch_divisor), last=None)
+        self.check_labels = bool(check_labels)
+
+    @property
+    def last(self):
+        """Device tensors of the latest call: per_image [2,B], num_pos [B], status [1]."""
+        return self.cfg["last"]
+
+    def forward(self, classifications, regressions, anchors, annotations):
+        cls_loss, reg_loss = _DenseHeadLossFn.apply(classifications, regressions, anchors,
+                                                    annotations, self.cfg)
+        if self.check_labels:
+            if int(self.cfg["last"]["status"].item()) & _lib.RH_STATUS_LABEL_RANGE:
+                raise IndexError("annotation label outside [0, num_classes)")
+        return {"classification_loss": cls_loss, "regression_loss": reg_loss}
+
+
+class _GenericFocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, alpha, gamma, logits, reduce):
+        loss, grad = F.generic_focal_fwd_bwd(inputs, targets, alpha, gamma, logits, reduce)
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = inputs.dtype
+        return loss.clone() if reduce else loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).to(ctx.in_dtype), None, None, None, None, None
+
+
+class GenericFocalLoss(nn.Module):
+    """Replaces FocalLoss (models/focal_loss.py:6-25): alpha*(1-pt)^gamma*BCE on logits or
+    probabilities, mean over all elements when ``reduce``."""
+
+    def __init__(self, alpha=0.25, gamma=2, logits=True, reduce=True):
+        super().__init__()
+        self.alpha, self.gamma, self.logits, self.reduce = alpha, gamma, logits, reduce
+
+    def forward(self, inputs, targets):
+        return _GenericFocalFn.apply(inputs, targets, float(self.alpha), float(self.gamma),
+                                     bool(self.logits), bool(self.reduce))
+
+
+class Anchors(nn.Module):
+    """Replaces Anchors (models/retinanet/anchors.py:6-45).
+
+    ``forward(image[B,3,H,W])`` returns float32 ``[1,N,4]`` on ``image.device``;
+    only the image's spatial shape is read.  Results are cached per (H, W, device).
+    Unlike the reference constructor (which keeps a passed argument only when it is
+    None, anchors.py:11-20) explicit levels / strides / sizes / ratios / scales are honoured.
+    """
+
+    def __init__(self, pyramid_levels=None, strides=None, sizes=None, ratios=None, scales=None):
+        super().__init__()
+        self.pyramid_levels = [3, 4, 5, 6, 7] if pyramid_levels is None else list(pyramid_levels)
+        self.strides = [2 ** x for x in self.pyramid_levels] if strides is None else list(strides)
+        self.sizes = [2 ** (x + 2) for x in self.pyramid_levels] if sizes is None else list(sizes)
+        self.ratios = np.array([0.5, 1, 2]) if ratios is None else np.asarray(ratios, np.float64)
+        self.scales = (np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)]) if scales is None
+                       else np.asarray(scales, np.float64))
+        self._cfg = None
+        self._cache = {}
+
+    def _config(self):
+        if self._cfg is None:
+            self._cfg = F.make_anchor_cfg(self.pyramid_levels, self.strides, self.sizes,
+                                          self.ratios, self.scales)
+        return self._cfg
+
+    def num_anchors(self, height, width):
+        return F.anchor_count(self._config(), height, width)
+
+    def forward(self, image):
+        h, w = int(image.shape[2]), int(image.shape[3])
+        key = (h, w, image.device)
+        hit = self._cache.get(key)
+        if hit is None:
+            hit = F.anchors(self._config(), h, w, image.device)
+            if len(self._cache) > 64:
+                self._cache.clear()
+            self._cache[key] = hit
+        return hit
+
+
+class BBoxTransform(nn.Module):
+    """Replaces BBoxTransform (models/retinanet/utils.py:83-125)."""
+
+    def __init__(self, mean=None, std=None):
+        super().__init__()
+        self.mean = [0.0, 0.0, 0.0, 0.0] if mean is None else [float(x) for x in mean]
+        self.std = [0.1, 0.1, 0.2, 0.2] if std is None else [float(x) for x in std]
+
+    def forward(self, boxes, deltas):
+        return F.bbox_transform(boxes, deltas, self.mean, self.std)
+
+
+class ClipBoxes(nn.Module):
+    """Replaces ClipBoxes (models/retinanet/utils.py:128-142); clamps ``boxes`` in place."""
+
+    def __init__(self, width=None, height=None):
+        super().__init__()
+
+    def forward(self, boxes, img):
+        height, width = int(img.shape[2]), int(img.shape[3])
+        if boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.data_ptr() % 16 == 0:
+            return F.clip_boxes_(boxes, height, width)
+        tmp = F.clip_boxes_(boxes.float().contiguous().clone(), height, width)
+        boxes.copy_(tmp)
+        return boxes
+
+
+def nms(boxes, scores=None, iou_threshold=None):
+    """Replaces ``torchvision.ops.nms(boxes[K,4], scores[K] or [K,1], iou_threshold)`` as called at
+    models/retinanet/model.py:336.  The legacy form ``nms(dets[K,5], thresh)`` of the removed
+    extension (model.py:11-14, 335) is accepted too.  Returns int64 indices of the kept boxes in
+    descending score order."""
+    if iou_threshold is None:          # legacy (dets, thresh)
+        dets, thresh = boxes, scores
+        if dets.dim() != 2 or dets.shape[1] != 5:
+            raise RetinaHeadError("legacy nms form expects dets [K,5] and a threshold")
+        return F.nms(dets[:, :4], dets[:, 4], float(thresh))
+    return F.nms(boxes, scores, float(iou_threshold))
+
+
+def batched_nms(boxes, scores, labels, iou_threshold):
+    """Per-class NMS: boxes only suppress boxes with the same label."""
+    return F.nms(boxes, scores, float(iou_threshold), labels=labels)
+
+
+def postprocess(classification, regression, anchors, img_batch, score_thresh=0.05, iou_thresh=0.5,
+                mode="agnostic", pre_nms_topk=None, max_det=None, max_candidates=4096,
+                output="dicts"):
+    """Inference post-processing for the whole batch; replaces models/retinanet/model.py:320-340.
+
+    classification [B,N,C] probabilities, regression [B,N,4], anchors [1,N,4]; ``img_batch`` is the
+    image tensor [B,3,H,W] (only its shape is read) or an ``(H, W)`` pair.
+    mode 'agnostic' is the reference behaviour (one NMS over all classes on the max-class score);
+    'per_class' lets only equal labels suppress each other.
+    Returns ``[{'boxes','labels','scores'}]`` per image (``output='dicts'``, the form
+    visualize.py:95-101 reads) or image 0's ``[scores, labels, boxes]`` (``output='tuple'``, the
+    form of model.py:340).  ``max_candidates`` sizes the first attempt's buffers; if an image has
+    more candidates over the threshold the call is repeated with room for all of them, so results
+    never depend on it.
+    """
+    if mode not in ("agnostic", "per_class"):
+        raise ValueError("mode must be 'agnostic' or 'per_class'")
+    if hasattr(img_batch, "shape"):
+        height, width = int(img_batch.shape[2]), int(img_batch.shape[3])
+    else:
+        height, width = int(img_batch[0]), int(img_batch[1])
+    n = classification.shape[1]
+    cap = min(n, int(max_candidates))
+    while True:
+        out = F.postprocess_raw(classification, regression, anchors, height, width, score_thresh,
+                                iou_thresh, mode == "per_class", pre_nms_topk or 0, max_det or 0, cap)
+        counts = out["counts"].cpu()          # the one host read: output sizes are data dependent
+        if int(counts[2].max()) == 0 or cap >= n:
+            break
+        cap = min(n, int(counts[1].max()))
+    kept = counts[0].tolist()
+    if output == "tuple":
+        k = kept[0]
+        return [out["scores"][0, :k], out["labels"][0, :k], out["boxes"][0, :k]]
+    return [{"boxes": out["boxes"][b, :k], "labels": out["labels"][b, :k],
+             "scores": out["scores"][b, :k]} for b, k in enumerate(kept)]

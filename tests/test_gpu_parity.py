@@ -1,0 +1,323 @@
+"""Parity of the HIP kernels (through the C ABI) with the golden vectors and the CPU oracle.
+
+Bars: anchors, IoU, assignments and NMS keep lists bit exact; losses and gradients
+within 1e-5 relative (float32).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dense_head_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+# Regression gradients: inside the quadratic zone of smooth-L1 the gradient is 9*(t - r), so a
+# one-ulp difference of log() in the target t (|t| up to a few units) moves it by 9*ulp(t) however
+# small t - r is; that is 4e-6 of the largest gradient (the linear zone's +-1), which is the floor
+# any float32 evaluation has.  Everything else uses 1e-7 of the largest value as absolute floor.
+REG_ATOL_REL = 4e-6
+
+
+@pytest.fixture(scope="module")
+def rh():
+    import retinahead
+    retinahead.load_library()
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return retinahead
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def grad_close(got, want, rtol=RTOL, atol_rel=1e-7):
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got, np.float64)
+    atol = atol_rel * float(np.max(np.abs(want))) if want.size else 0.0
+    bad = np.abs(got - want) > rtol * np.abs(want) + atol
+    assert not bad.any(), f"{bad.sum()} of {bad.size} elements off; worst abs {np.max(np.abs(got - want))}"
+    assert np.array_equal(got == 0, want == 0)
+
+
+# ------------------------------------------------------------------ anchors
+def test_anchors_golden(rh):
+    g = load_golden("anchors.npz")
+    mod = rh.Anchors()
+    for key in g.files:
+        if key.startswith("a_"):
+            _, h, w = key.split("_")
+            out = mod(torch.zeros(1, 3, int(h), int(w), device="cuda")).cpu().numpy()
+            assert out.shape == g[key].shape and np.array_equal(out, g[key]), key
+        if key.startswith("sha_"):
+            _, h, w = key.split("_")
+            out = mod(torch.zeros(2, 3, int(h), int(w), device="cuda")).cpu().numpy()
+            assert out.shape == (1, int(g[f"n_{h}_{w}"][0]), 4)
+            assert hashlib.sha256(out.tobytes()).digest() == g[key].tobytes(), key
+
+
+def test_anchors_custom_config(rh):
+    mod = rh.Anchors(pyramid_levels=[2, 4], ratios=[1.0, 3.0], scales=[1.0, 1.5, 2.0, 2.5])
+    out = mod(torch.zeros(1, 3, 50, 70, device="cuda")).cpu().numpy()
+    ref = O.anchors_for_image(50, 70, levels=(2, 4), ratios=(1.0, 3.0), scales=(1.0, 1.5, 2.0, 2.5))
+    assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------ IoU / assignment
+def test_calc_iou_golden(rh):
+    g = load_golden("calc_iou.npz")
+    out = rh.calc_iou(dev(g["a"]), dev(g["b"])).cpu().numpy()
+    assert np.array_equal(out, g["iou"])
+
+
+@pytest.mark.parametrize("case", ["normal", "holes", "no_pos", "ties", "clamp", "c1", "c13", "c80",
+                                  "m256", "handmade", "all_empty"])
+def test_assign_and_loss_golden(rh, focal_golden, case):
+    d = focal_golden[case]
+    bsz, n, c = d["cls"].shape
+    asg = rh.functional.assign(dev(d["anchors"]), dev(d["ann"]), c)
+    for j in range(bsz):
+        ref = O.assign(d["anchors"][0], d["ann"][j])
+        assert np.array_equal(asg["state"][j].cpu().numpy(), ref["state"])
+        assert np.array_equal(asg["label"][j].cpu().numpy(), ref["label"])
+        assert int(asg["num_pos"][j]) == ref["num_pos"] == int(d["num_pos"][j])
+        if ref["num_gt"]:
+            assert np.array_equal(asg["iou_max"][j].cpu().numpy(), d["iou_max"][j])
+            assert np.array_equal(asg["argmax"][j].cpu().numpy(), d["argmax"][j])
+    # loss + gradients through the autograd wrapper, upstream gradients as in the fixture
+    cls = dev(d["cls"]).requires_grad_(True)
+    reg = dev(d["reg"]).requires_grad_(True)
+    out = rh.FocalLoss()(cls, reg, dev(d["anchors"]), dev(d["ann"]))
+    assert out["classification_loss"].shape == (1,) and out["regression_loss"].shape == (1,)
+    total = float(d["g"][0]) * out["classification_loss"].sum() + float(d["g"][1]) * out["regression_loss"].sum()
+    total.backward()
+    assert np.allclose(out["classification_loss"].detach().cpu().numpy(), d["cls_loss"], rtol=RTOL, atol=0)
+    assert np.allclose(out["regression_loss"].detach().cpu().numpy(), d["reg_loss"], rtol=RTOL, atol=0)
+    grad_close(cls.grad.cpu().numpy(), d["d_cls"])
+    grad_close(reg.grad.cpu().numpy(), d["d_reg"], atol_rel=REG_ATOL_REL)
+
+
+def make_batch(seed, bsz, size, c, m, valid):
+    rng = np.random.default_rng(seed)
+    anc = O.anchors_for_image(size, size)
+    n = anc.shape[1]
+    z = rng.normal(-4.595, 2.0, (bsz, n, c))
+    cls = (1.0 / (1.0 + np.exp(-z))).astype(np.float32)
+    reg = rng.normal(0, 1, (bsz, n, 4)).astype(np.float32)
+    ann = -np.ones((bsz, m, 5), np.float32)
+    for j in range(bsz):
+        v = valid[j % len(valid)]
+        cx, cy = rng.uniform(0, size, v), rng.uniform(0, size, v)
+        w = np.exp(rng.uniform(np.log(16), np.log(size / 2), v))
+        h = np.exp(rng.uniform(np.log(16), np.log(size / 2), v))
+        x1, y1 = np.clip(cx - w / 2, 0, size - 1), np.clip(cy - h / 2, 0, size - 1)
+        x2, y2 = np.clip(cx + w / 2, x1 + 1, size), np.clip(cy + h / 2, y1 + 1, size)
+        ann[j, :v, :4] = np.stack([x1, y1, x2, y2], 1)
+        ann[j, :v, 4] = rng.integers(0, c, v)
+    return cls, reg, anc, ann
+
+
+@pytest.mark.parametrize("bsz,size,c,m,valid", [
+    (3, 256, 80, 8, [8, 0, 3]),      # COCO-like, an empty image in the middle
+    (2, 160, 601, 6, [6, 2]),        # rows of 2404 bytes: float4 accesses straddle rows
+    (2, 96, 5, 4, [4, 1]),           # C not a multiple of 4
+    (1, 64, 3, 4, [3]),              # C < 4: generic row kernel
+    (2, 320, 80, 256, [256, 100]),   # dense GT, several LDS chunks
+])
+def test_loss_vs_oracle(rh, bsz, size, c, m, valid):
+    cls, reg, anc, ann = make_batch(7 + c, bsz, size, c, m, valid)
+    ref = O.focal_loss_fwd_bwd(cls, reg, anc, ann, grad_cls=1.0, grad_reg=1.0)
+    out = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
+    torch.cuda.synchronize()
+    assert np.array_equal(out["num_pos"].cpu().numpy(), ref["num_pos"])
+    assert int(out["status"]) == 0
+    assert np.allclose(out["losses"].cpu().numpy(),
+                       [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
+    pi = out["per_image"].cpu().numpy()
+    assert np.allclose(pi[0], ref["cls_per_image"], rtol=RTOL, atol=0)
+    assert np.allclose(pi[1], ref["reg_per_image"], rtol=RTOL, atol=0)
+    grad_close(out["d_classifications"].cpu().numpy(), ref["d_classifications"])
+    grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+
+
+def test_loss_deterministic_and_unaligned(rh):
+    cls, reg, anc, ann = make_batch(3, 2, 128, 80, 5, [5, 2])
+    a = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
+    la, ga = a["losses"].cpu().numpy().copy(), a["d_classifications"].cpu().numpy().copy()
+    b = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
+    assert np.array_equal(la, b["losses"].cpu().numpy())          # bitwise reproducible
+    assert np.array_equal(ga, b["d_classifications"].cpu().numpy())
+    # a misaligned view goes through the wrapper's copy and gives the same bits
+    pad = torch.zeros(cls.size + 1, device="cuda")
+    pad[1:] = dev(cls).reshape(-1)
+    view = pad[1:].view(cls.shape)
+    assert view.data_ptr() % 16 != 0
+    c = rh.functional.focal_loss_fwd_bwd(view, dev(reg), dev(anc), dev(ann))
+    assert np.array_equal(la, c["losses"].cpu().numpy())
+
+
+def test_loss_batch_divisor_and_expected_grad(rh):
+    cls, reg, anc, ann = make_batch(5, 4, 96, 7, 4, [4, 2, 0, 3])
+    ref = O.focal_loss_fwd_bwd(cls, reg, anc, ann, grad_cls=0.25, grad_reg=0.25)
+    # two "ranks" with two images each, batch_divisor = 4: losses add up, gradients concatenate
+    parts = []
+    for lo in (0, 2):
+        t = dev(cls[lo:lo + 2]).requires_grad_(True)
+        r = dev(reg[lo:lo + 2]).requires_grad_(True)
+        mod = rh.FocalLoss(batch_divisor=4, expected_grad=0.25)
+        o = mod(t, r, dev(anc), dev(ann[lo:lo + 2]))
+        ((o["classification_loss"] + o["regression_loss"]) * 0.25).sum().backward()
+        parts.append((o, t.grad.cpu().numpy(), r.grad.cpu().numpy()))
+    cl = sum(float(p[0]["classification_loss"]) for p in parts)
+    rl = sum(float(p[0]["regression_loss"]) for p in parts)
+    assert np.isclose(cl, ref["classification_loss"][0], rtol=RTOL)
+    assert np.isclose(rl, ref["regression_loss"][0], rtol=RTOL)
+    grad_close(np.concatenate([p[1] for p in parts]), ref["d_classifications"])
+    grad_close(np.concatenate([p[2] for p in parts]), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+
+
+def test_label_out_of_range_flag(rh):
+    cls, reg, anc, ann = make_batch(9, 1, 64, 4, 3, [3])
+    ann[0, 1, 4] = 4.0                                   # == C: IndexError in the reference
+    with pytest.raises(IndexError):
+        rh.FocalLoss(check_labels=True)(dev(cls), dev(reg), dev(anc), dev(ann))
+
+
+def test_cpu_tensor_rejected(rh):
+    cls, reg, anc, ann = make_batch(9, 1, 64, 4, 3, [3])
+    with pytest.raises(rh.RetinaHeadError):
+        rh.FocalLoss()(torch.from_numpy(cls), torch.from_numpy(reg), torch.from_numpy(anc),
+                       torch.from_numpy(ann))
+
+
+# ------------------------------------------------------------------ generic focal
+def test_generic_focal_golden(rh):
+    g = load_golden("generic_focal.npz")
+    t = dev(g["targets"])
+    for logits in (True, False):
+        for reduce in (True, False):
+            key = f"{'logits' if logits else 'probs'}_{'mean' if reduce else 'none'}"
+            x = dev(g[key + ".inp"]).requires_grad_(True)
+            out = rh.GenericFocalLoss(logits=logits, reduce=reduce)(x, t)
+            out.sum().backward()
+            assert np.allclose(out.detach().cpu().numpy(), g[key + ".loss"], rtol=2e-5, atol=1e-7), key
+            assert np.allclose(x.grad.cpu().numpy(), g[key + ".grad"], rtol=2e-4,
+                               atol=1e-6 if not reduce else 1e-8), key
+
+
+# ------------------------------------------------------------------ decode / clip
+def test_decode_clip_golden(rh):
+    g = load_golden("decode.npz")
+    dec = rh.BBoxTransform()(dev(g["anchors"]), dev(g["deltas"]))
+    scale = np.max(np.abs(g["decoded"]), axis=2, keepdims=True)
+    assert (np.abs(dec.cpu().numpy().astype(np.float64) - g["decoded"]) <= 1e-6 * scale).all()
+    h, w = int(g["hw"][0]), int(g["hw"][1])
+    boxes = dev(g["decoded"])
+    ret = rh.ClipBoxes()(boxes, torch.zeros(3, 3, h, w, device="cuda"))
+    assert ret.data_ptr() == boxes.data_ptr()            # in place, like the reference
+    assert np.array_equal(boxes.cpu().numpy(), g["clipped"])
+
+
+# ------------------------------------------------------------------ NMS
+def rand_dets(seed, k, size=200.0, cluster=True):
+    rng = np.random.default_rng(seed)
+    if cluster:
+        centers = rng.uniform(0, size, (max(k // 8, 1), 2))
+        c = centers[rng.integers(0, centers.shape[0], k)] + rng.normal(0, 4, (k, 2))
+    else:
+        c = rng.uniform(0, size, (k, 2))
+    wh = rng.uniform(8, 40, (k, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    scores = rng.random(k).astype(np.float32)
+    return boxes, scores
+
+
+@pytest.mark.parametrize("k", [1, 2, 63, 64, 65, 500, 2000, 5000])
+def test_nms_vs_oracle(rh, k):
+    boxes, scores = rand_dets(k, k)
+    scores[: k // 3] = scores[k // 3: 2 * (k // 3)]      # score ties: lower index first
+    keep = rh.nms(dev(boxes), dev(scores), 0.5).cpu().numpy()
+    assert keep.dtype == np.int64
+    assert np.array_equal(keep, O.nms(boxes, scores, 0.5))
+    keep2 = rh.nms(dev(boxes), dev(scores[:, None]), 0.3).cpu().numpy()   # [K,1] scores (model.py:336)
+    assert np.array_equal(keep2, O.nms(boxes, scores, 0.3))
+
+
+def test_nms_legacy_and_per_class(rh):
+    boxes, scores = rand_dets(77, 700)
+    dets = np.concatenate([boxes, scores[:, None]], 1)
+    assert np.array_equal(rh.nms(dev(dets), 0.4).cpu().numpy(), O.nms(boxes, scores, 0.4))
+    labels = np.random.default_rng(1).integers(0, 5, 700)
+    got = rh.batched_nms(dev(boxes), dev(scores), dev(labels), 0.5).cpu().numpy()
+    assert np.array_equal(got, O.nms(boxes, scores, 0.5, labels=labels))
+
+
+def test_nms_large_global_sort(rh):
+    boxes, scores = rand_dets(5, 20000, size=3000.0)     # beyond the LDS sort: global bitonic path
+    keep = rh.nms(dev(boxes), dev(scores), 0.5).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes, scores, 0.5))
+
+
+def test_nms_empty_and_degenerate(rh):
+    assert rh.nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"), 0.5).numel() == 0
+    boxes = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [5, 5, 5, 5], [5, 5, 5, 5], [0, 0, 10, 5.0]], np.float32)
+    scores = np.array([0.9, 0.9, 0.5, 0.4, 0.3], np.float32)
+    keep = rh.nms(dev(boxes), dev(scores), 0.5).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes, scores, 0.5))
+    assert np.array_equal(keep, O.nms_bruteforce(boxes, scores, 0.5))
+
+
+# ------------------------------------------------------------------ post-processing
+def infer_batch(seed, bsz, size, c, mu=-5.0):
+    rng = np.random.default_rng(seed)
+    anc = O.anchors_for_image(size, size)
+    n = anc.shape[1]
+    z = rng.normal(mu, 1.2, (bsz, n, c))
+    cls = (1.0 / (1.0 + np.exp(-z))).astype(np.float32)
+    reg = rng.normal(0, 0.5, (bsz, n, 4)).astype(np.float32)
+    return cls, reg, anc
+
+
+def check_post(rh, cls, reg, anc, size, **kw):
+    res = rh.postprocess(dev(cls), dev(reg), dev(anc), (size, size), **kw)
+    okw = {k: v for k, v in kw.items() if k != "max_candidates"}
+    # the device's own decode + clip (checked against the oracle's to 1e-6 of the box scale) feeds
+    # the oracle's NMS, so keep lists compare exactly even where exp() differs in the last place
+    dboxes = rh.ClipBoxes()(rh.BBoxTransform()(dev(anc), dev(reg)),
+                            torch.zeros(1, 3, size, size, device="cuda")).cpu().numpy()
+    oboxes = O.clip_boxes(O.bbox_transform(anc, reg), size, size)
+    scale = np.maximum(np.max(np.abs(oboxes), axis=2, keepdims=True), 1.0)
+    assert (np.abs(dboxes.astype(np.float64) - oboxes) <= 1e-6 * scale).all()
+    for b in range(cls.shape[0]):
+        s, l, bx = O.postprocess_image(cls[b], reg[b], anc, size, size, boxes=dboxes[b], **okw)
+        got = res[b]
+        assert np.array_equal(got["labels"].cpu().numpy(), l), f"image {b}"
+        assert np.array_equal(got["scores"].cpu().numpy(), s)
+        assert np.array_equal(got["boxes"].cpu().numpy(), bx)
+    return res
+
+
+def test_postprocess_agnostic(rh):
+    cls, reg, anc = infer_batch(1, 3, 256, 80)
+    cls[1] = 0.01                                        # image without candidates
+    res = check_post(rh, cls, reg, anc, 256)
+    assert res[1]["scores"].numel() == 0 and res[1]["boxes"].shape == (0, 4)
+    tup = rh.postprocess(dev(cls), dev(reg), dev(anc), torch.zeros(3, 3, 256, 256), output="tuple")
+    assert len(tup) == 3 and torch.equal(tup[0], res[0]["scores"])
+
+
+def test_postprocess_per_class_topk_maxdet(rh):
+    cls, reg, anc = infer_batch(2, 2, 192, 13, mu=-4.0)
+    check_post(rh, cls, reg, anc, 192, mode="per_class")
+    check_post(rh, cls, reg, anc, 192, mode="per_class", pre_nms_topk=300)
+    check_post(rh, cls, reg, anc, 192, pre_nms_topk=1000, max_det=50)
+
+
+def test_postprocess_overflow_retry_and_odd_classes(rh):
+    cls, reg, anc = infer_batch(3, 2, 128, 601, mu=-7.0)
+    check_post(rh, cls, reg, anc, 128, max_candidates=64)      # forces the exact second pass
+    cls, reg, anc = infer_batch(4, 1, 64, 3, mu=-2.0)          # C < 4: generic kernel
+    check_post(rh, cls, reg, anc, 64)
