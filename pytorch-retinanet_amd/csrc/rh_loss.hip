@@ -198,23 +198,44 @@ struct FocalConst {
   float lo, hi;      // clamp bounds (losses.py:57)
 };
 
-// Loss and d(loss)/dp of one element.  `one`: target is 1; otherwise 0.
-//   target 1: L = a (1-p)^2 (-ln p)      dL/dp =  a [2(1-p) ln p - (1-p)^2 / p]
-//   target 0: L = (1-a) p^2 (-ln(1-p))   dL/dp = -(1-a) [2p ln(1-p) - p^2 / (1-p)]
-// Outside [lo, hi] the clamp blocks the gradient (inclusive bounds pass it).
-__device__ __forceinline__ void focal_elem(const float p, const bool one, const FocalConst k,
-                                           float& loss, float& grad) {
-  const float pc = fminf(fmaxf(p, k.lo), k.hi);
-  const float q = 1.0f - pc;
-  const float u = one ? q : pc;    // focal base
-  const float w = one ? pc : q;    // argument of the log
-  const float a = one ? k.alpha : 1.0f - k.alpha;
-  const float lw = logf(w);
+constexpr float kLn2 = 0.693147180559945f;
+
+// The stream is VALU-sensitive (one log and one divide per element), so the element
+// maths uses the hardware's 1-ulp log2 and reciprocal (v_log_f32, v_rcp_f32) with the
+// constant factors folded: a handful of ulps (< 1e-6 relative), against a 1e-5 bar.
+// Arguments stay in [1e-4, 1 - 1e-4]: no denormal or range handling is needed.
+//
+//   target 1 (u = 1-p, w = p):    L = a u^2 (-ln w)       dL/dp =  a [2u ln w - u^2 / w]
+//   target 0 (u = p, w = 1-p):    L = (1-a) u^2 (-ln w)   dL/dp = -(1-a) [2u ln w - u^2 / w]
+// Outside [lo, hi] the clamp blocks the gradient (inclusive bounds pass it): the clamp
+// changes p exactly when p is outside, so "pc == p" is the pass condition.
+//
+// kl = -a ln2 and kg = +-a * scale are formed by the caller (per target kind).
+__device__ __forceinline__ float focal_core(const float p, const float pc, const float u,
+                                            const float w, const float kl, const float kg,
+                                            float& grad) {
+  const float lg = __builtin_amdgcn_logf(w);          // log2(w)
   const float uu = u * u;
-  loss = (a * uu) * (-lw);
-  float g = a * ((2.0f * u) * lw - uu / w);
-  g = one ? g : -g;
-  grad = (p >= k.lo && p <= k.hi) ? g : 0.0f;
+  const float t = uu * __builtin_amdgcn_rcpf(w);
+  const float g = kg * __builtin_fmaf(u, lg * (2.0f * kLn2), -t);
+  grad = (pc == p) ? g : 0.0f;
+  return uu * (lg * kl);
+}
+
+// Target-0 element (the overwhelmingly common case).  k0l = -(1-a) ln2, k0g = -(1-a)*scale.
+__device__ __forceinline__ float focal_zero(const float p, const FocalConst k, const float k0l,
+                                            const float k0g, float& grad) {
+  const float pc = __builtin_amdgcn_fmed3f(p, k.lo, k.hi);
+  return focal_core(p, pc, pc, 1.0f - pc, k0l, k0g, grad);
+}
+
+// Either target.  scale multiplies the gradient.
+__device__ __forceinline__ float focal_any(const float p, const bool one, const FocalConst k,
+                                           const float scale, float& grad) {
+  const float pc = __builtin_amdgcn_fmed3f(p, k.lo, k.hi);
+  const float q = 1.0f - pc;
+  const float a = one ? k.alpha : 1.0f - k.alpha;
+  return focal_core(p, pc, one ? q : pc, one ? pc : q, -a * kLn2, (one ? a : -a) * scale, grad);
 }
 
 // Smooth-L1 of one regression coordinate of a positive anchor (losses.py:101-133).
@@ -273,6 +294,8 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
   const int tid = threadIdx.x;
+  const float k0l = -(1.0f - fc.alpha) * kLn2;
+  constexpr int UG = 2;   // unroll of the general (row-tracking) path: keeps registers low
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     const int row0 = tile * kTileRows;
@@ -286,31 +309,37 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float sc0 = gcls / (norm0 * divisor), sc1 = gcls / (norm1 * divisor);
 
     __syncthreads();   // previous tile's readers of s_code / s_red are done
-    if (tid < kTileRows) s_code[tid] = tid < rows ? code[row0 + tid] : kCodeIgn;
+    int my_code = kCodeNeg;
+    if (tid < rows) my_code = code[row0 + tid];
+    if (tid < kTileRows) s_code[tid] = tid < rows ? my_code : kCodeIgn;
+    // any positive or ignored row in this tile?  (also the barrier that publishes s_code)
+    const int special = __syncthreads_or(my_code != kCodeNeg);
+
+    float cl0 = 0.f, cl1 = 0.f, rl0 = 0.f, rl1 = 0.f;
 
     // ---- regression: 4 lanes per anchor, one coordinate each -----------------
-    float rl0 = 0.f, rl1 = 0.f;
     {
       const int r = tid >> 2, k = tid & 3;
       if (r < rows) {
         const int grow = row0 + r;
-        const int cd = code[grow];
         float g = 0.f;
-        if (cd >= 0) {
-          const bool second = r >= split;
-          const int j = second ? j0 + 1 : j0;
-          const float cnt4 = 4.0f * (float)(second ? np1 : np0);
-          const float rv = reg[(size_t)grow * 4 + k];
-          float gr;
-          const float l = smooth_l1_coord(k, anchors[grow - j * N], gt[(size_t)j * M + (cd >> 16)],
-                                          rv, &gr);
-          g = gr * (greg / (cnt4 * divisor));
-          if (second) rl1 = l; else rl0 = l;
+        if (special) {
+          const int cd = s_code[r];
+          if (cd >= 0) {
+            const bool second = r >= split;
+            const int j = second ? j0 + 1 : j0;
+            const float cnt4 = 4.0f * (float)(second ? np1 : np0);
+            const float rv = reg[(size_t)grow * 4 + k];
+            float gr;
+            const float l = smooth_l1_coord(k, anchors[grow - j * N],
+                                            gt[(size_t)j * M + (cd >> 16)], rv, &gr);
+            g = gr * (greg / (cnt4 * divisor));
+            if (second) rl1 = l; else rl0 = l;
+          }
         }
         __builtin_nontemporal_store(g, &dreg[(size_t)grow * 4 + k]);
       }
     }
-    __syncthreads();
 
     // ---- classification stream ----------------------------------------------
     const size_t base = (size_t)row0 * C;
@@ -318,46 +347,72 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     v4f* __restrict__ d4 = reinterpret_cast<v4f*>(dprob + base);
     const int elems = rows * C;
     const int nvec = elems >> 2;
-    float cl0 = 0.f, cl1 = 0.f;
 
-    for (int v0 = tid; v0 < nvec; v0 += kThreads * U) {
-      v4f val[U];
+    if (!special && !two) {
+      // Every row is a negative of one image: pure elementwise stream, no index maths.
+      const float k0g = -(1.0f - fc.alpha) * sc0;
+      for (int v0 = tid; v0 < nvec; v0 += kThreads * U) {
+        v4f val[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int v = v0 + u * kThreads;
-        if (v < nvec) val[u] = p4[v];
-      }
+        for (int u = 0; u < U; ++u) {
+          const int v = v0 + u * kThreads;
+          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int v = v0 + u * kThreads;
-        if (v < nvec) {
-          const unsigned x = (unsigned)v << 2;
-          int r = (int)fast_div(x, magic_c);
-          int col = (int)x - r * C;
-          const float in[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
-          float out[4];
-          int cd = s_code[r];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (col >= C) {            // C >= 4: at most one row change per float4
-              col -= C;
-              r += 1;
-              cd = s_code[r];
-            }
-            const bool one = cd >= 0 && (cd & 0xFFFF) == col;
-            float l, g;
-            focal_elem(in[e], one, fc, l, g);
-            const bool second = r >= split;
-            const bool live = cd != kCodeIgn;
-            l = live ? l : 0.f;
-            out[e] = live ? g * (second ? sc1 : sc0) : 0.f;
-            cl0 += second ? 0.f : l;
-            cl1 += second ? l : 0.f;
-            col += 1;
+        for (int u = 0; u < U; ++u) {
+          const int v = v0 + u * kThreads;
+          if (v < nvec) {
+            float g0, g1, g2, g3;
+            cl0 += focal_zero(val[u].x, fc, k0l, k0g, g0);
+            cl0 += focal_zero(val[u].y, fc, k0l, k0g, g1);
+            cl0 += focal_zero(val[u].z, fc, k0l, k0g, g2);
+            cl0 += focal_zero(val[u].w, fc, k0l, k0g, g3);
+            v4f o;
+            o.x = g0; o.y = g1; o.z = g2; o.w = g3;
+            __builtin_nontemporal_store(o, &d4[v]);
           }
-          v4f o;
-          o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
-          __builtin_nontemporal_store(o, &d4[v]);
+        }
+      }
+    } else {
+      for (int v0 = tid; v0 < nvec; v0 += kThreads * UG) {
+        v4f val[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+          const int v = v0 + u * kThreads;
+          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+          const int v = v0 + u * kThreads;
+          if (v < nvec) {
+            const unsigned x = (unsigned)v << 2;
+            int r = (int)fast_div(x, magic_c);
+            int col = (int)x - r * C;
+            const float in[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
+            float out[4];
+            int cd = s_code[r];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (col >= C) {            // C >= 4: at most one row change per float4
+                col -= C;
+                r += 1;
+                cd = s_code[r];
+              }
+              const bool one = cd >= 0 && (cd & 0xFFFF) == col;
+              const bool second = r >= split;
+              const bool live = cd != kCodeIgn;
+              float g;
+              float l = focal_any(in[e], one, fc, second ? sc1 : sc0, g);
+              l = live ? l : 0.f;
+              out[e] = live ? g : 0.f;
+              cl0 += second ? 0.f : l;
+              cl1 += second ? l : 0.f;
+              col += 1;
+            }
+            v4f o;
+            o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+            __builtin_nontemporal_store(o, &d4[v]);
+          }
         }
       }
     }
@@ -368,11 +423,11 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
         const int r = x / C, col = x - r * C;
         const int cd = s_code[r];
         const bool one = cd >= 0 && (cd & 0xFFFF) == col;
-        float l, g;
-        focal_elem(prob[base + x], one, fc, l, g);
         const bool second = r >= split;
         const bool live = cd != kCodeIgn;
-        dprob[base + x] = live ? g * (second ? sc1 : sc0) : 0.f;
+        float g;
+        float l = focal_any(prob[base + x], one, fc, second ? sc1 : sc0, g);
+        dprob[base + x] = live ? g : 0.f;
         l = live ? l : 0.f;
         cl0 += second ? 0.f : l;
         cl1 += second ? l : 0.f;
@@ -421,9 +476,9 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
     const float* p = prob + row * C;
     float* d = dprob + row * C;
     for (int c = lane; c < C; c += 64) {
-      float l, g;
-      focal_elem(p[c], cd >= 0 && (cd & 0xFFFF) == c, fc, l, g);
-      d[c] = live ? g * sc : 0.f;
+      float g;
+      const float l = focal_any(p[c], cd >= 0 && (cd & 0xFFFF) == c, fc, sc, g);
+      d[c] = live ? g : 0.f;
       cl += live ? l : 0.f;
     }
     if (lane < 4) {
@@ -678,7 +733,11 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   if (stages & RH_STAGE_STREAM) {
     if (tile) {
       const int grid = num_tiles < 256 * 8 ? num_tiles : 256 * 8;
-      hipLaunchKernelGGL(focal_stream_kernel<4>, dim3(grid), dim3(kThreads), 0, s, classifications,
+      // float4 slots per thread and tile: pick the unroll that wastes the fewest
+      const int per_thread = (kTileRows * num_classes / 4 + kThreads - 1) / kThreads;
+      const bool u5 = (per_thread + 4) / 5 * 5 < (per_thread + 3) / 4 * 4;
+      auto kern = u5 ? focal_stream_kernel<5> : focal_stream_kernel<4>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, classifications,
                          d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.num_pos,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,

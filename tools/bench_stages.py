@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-stage HIP-event timings of the loss and post-processing kernels for the benchmark
+configurations (2: COCO-80 608 B=16, 3: 601 classes 800 px B=8, 4: 256 GT 1024 px B=4)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pytorch-retinanet_amd")):
+    sys.path.insert(0, p)
+import bench  # noqa: E402
+import retinahead as rh  # noqa: E402
+from retinahead import _lib, functional as F  # noqa: E402
+
+CFG = {2: (16, 608, 80, 20), 3: (8, 800, 601, 8), 4: (4, 1024, 80, 256)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--infer", action="store_true")
+    a = ap.parse_args()
+    bsz, size, c, m = CFG[a.cfg]
+    dev = torch.device("cuda:0")
+    anchors = rh.Anchors()(torch.zeros(1, 3, size, size, device=dev))
+    n = anchors.shape[1]
+    rng = np.random.default_rng(1000 * a.cfg)
+    if not a.infer:
+        cls_np, reg_np, ann_np = bench.synth_train(rng, bsz, n, c, size, m)
+        if a.cfg == 4:   # every row valid
+            pass
+        cls, reg, ann = (torch.from_numpy(x).to(dev) for x in (cls_np, reg_np, ann_np))
+        bufs = F.focal_loss_fwd_bwd(cls, reg, anchors, ann)
+        print("num_pos", bufs["num_pos"].cpu().numpy().tolist())
+        algo = bsz * n * (8 * c + 48)
+        for name, st in (("assign", _lib.STAGE_ASSIGN), ("stream", _lib.STAGE_STREAM),
+                         ("finalize", _lib.STAGE_FINALIZE), ("all", _lib.STAGE_ALL)):
+            fn = lambda: F.focal_loss_fwd_bwd(cls, reg, anchors, ann, stages=st, out=bufs)
+            for _ in range(10):
+                fn()
+            mean, mn = bench.event_times(fn, a.iters)
+            extra = f"  algo {algo / mean / 1e6:8.1f} GB/s (mean) {algo / mn / 1e6:8.1f} (min)" \
+                if name in ("stream", "all") else ""
+            print(f"{name:9s} mean {mean * 1e3:8.1f} us  min {mn * 1e3:8.1f} us{extra}")
+    else:
+        icls_np, ireg_np = bench.synth_infer(rng, bsz, n, c)
+        icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
+        res = F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=4096)
+        print("counts", res["counts"].cpu().numpy()[:, :4].tolist())
+        algo = bsz * n * (4 * c + 32)
+        for name, st in (("decode", _lib.POST_DECODE), ("sort", _lib.POST_SORT),
+                         ("nms", _lib.POST_NMS), ("all", _lib.POST_ALL)):
+            fn = lambda: F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=4096, stages=st,
+                                           out=res)
+            for _ in range(5):
+                fn()
+            mean, mn = bench.event_times(fn, a.iters)
+            extra = f"  algo {algo / mean / 1e6:8.1f} GB/s" if name in ("decode", "all") else ""
+            print(f"{name:9s} mean {mean * 1e3:8.1f} us  min {mn * 1e3:8.1f} us{extra}")
+
+
+if __name__ == "__main__":
+    main()
