@@ -129,7 +129,8 @@ def main():
         cls.grad = None
         reg.grad = None
         out = step_mod(cls, reg, anchors, ann)
-        (out["classification_loss"] + out["regression_loss"]).sum().backward()
+        loss = sum(l for l in out.values())      # train.py:185
+        loss.backward()                          # train.py:190
         return out
 
     def fence():

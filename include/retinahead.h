@@ -45,7 +45,7 @@ enum rh_status {
 /* Per-anchor assignment states written by rh_assign (losses.py:70-72). */
 enum rh_anchor_state { RH_NEGATIVE = 0, RH_IGNORE = 1, RH_POSITIVE = 2 };
 
-/* Bits of the device status word written by the loss entry points. */
+/* Bits of the per-image device status words written by the loss entry points. */
 enum rh_status_bits {
   RH_STATUS_LABEL_RANGE = 1 /* a valid GT row has a label outside [0, C): the
                                reference raises IndexError at losses.py:79; here
@@ -101,7 +101,8 @@ int rh_calc_iou_f32(const float* a, int64_t n, const float* b, int64_t m, float*
  *   label        device i32 [B,N]  class of positives, -1 otherwise
  *   iou_max      device f32 [B,N]
  *   num_pos      device i32 [B]
- * Any of state/argmax/label/iou_max may be NULL.  status: device i32 [1] or NULL.
+ * Any of state/argmax/label/iou_max may be NULL.  status: device i32 [B] (rh_status_bits per
+ * image, written by every call) or NULL.
  * ------------------------------------------------------------------------- */
 size_t rh_assign_workspace_bytes(int32_t batch, int64_t n, int32_t m);
 int rh_assign(const float* anchors, const float* annotations, int32_t batch, int64_t n, int32_t m,
@@ -121,7 +122,7 @@ int rh_assign(const float* anchors, const float* annotations, int32_t batch, int
  *   losses          device f32 [2]  {classification_loss, regression_loss} (batch means, :139-141)
  *   per_image       device f32 [2,B] or NULL  (per-image losses, :94 and :134)
  *   num_pos         device i32 [B] or NULL
- *   status          device i32 [1] or NULL  (rh_status_bits, OR-ed in)
+ *   status          device i32 [B] or NULL  (rh_status_bits per image, written by every call)
  * batch_divisor: number of images the batch mean runs over; 0 means B.  A
  * data-parallel shard passes the global batch size.
  * ------------------------------------------------------------------------- */
@@ -152,11 +153,13 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                           float* per_image, int32_t* num_pos, int32_t* status, void* workspace,
                           size_t workspace_bytes, int32_t stages, rh_stream_t stream);
 
-/* In-place x *= (*scale_dev) / assumed over count floats; returns without touching memory
- * traffic when *scale_dev == assumed.  Used by the autograd wrapper to apply an upstream
- * gradient (train.py:185-190) to the stored gradients without a host read. */
-int rh_scale_inplace_f32(float* x, int64_t count, const float* scale_dev, float assumed,
-                         rh_stream_t stream);
+/* Applies upstream gradients to the stored gradients without a host read:
+ * x *= (*scale_x) / assumed and y *= (*scale_y) / assumed, in place, one launch.  An array whose
+ * scale equals `assumed` is not touched (no memory traffic); a NULL scale pointer zeroes the
+ * array (that loss took no part in the backward pass); a NULL array is skipped.  scale_x /
+ * scale_y are device f32 [1].  Used by the autograd wrapper for train.py:185-190. */
+int rh_apply_upstream_f32(float* x, int64_t nx, const float* scale_x, float* y, int64_t ny,
+                          const float* scale_y, float assumed, rh_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Generic elementwise focal BCE, forward + backward  -  replaces

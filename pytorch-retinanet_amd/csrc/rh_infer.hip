@@ -20,7 +20,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;
 constexpr int kTileRows = 64;
 constexpr int kSortThreads = 1024;
-constexpr int kLdsSortMax = 16384;   // keys of 8 bytes: 128 KiB of the CU's 160 KiB LDS
+constexpr int kLdsSortMax = 16384;
+constexpr int kCounterStride = 32;  // ints: per-image counters sit in separate 128-byte lines   // keys of 8 bytes: 128 KiB of the CU's 160 KiB LDS
 
 // Order-preserving map float32 -> uint32 (larger float <=> larger key) and back.
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -90,28 +91,50 @@ struct CandOut {
   u64* keys;            // [B][key_stride]
   float4* dense_box;    // [B*N]
   int* dense_label;     // [B*N]
-  int* cand_count;      // [B]
-  int* overflow;        // [B]
+  int* cand_count;      // [B][kCounterStride]: one counter per 128-byte line
+  int* overflow;        // [B][kCounterStride]
   int cap;
   int key_stride;
 };
 
-__device__ __forceinline__ void emit_candidate(const u64 best, const int j, const int n, const int N,
-                                               const float4* __restrict__ anchors,
-                                               const float* __restrict__ reg, const BoxCoder bc,
-                                               const float width, const float height,
-                                               const float thresh, const CandOut o) {
+// Called by ALL 64 lanes of one wave (lane = tile row); rows of one tile belong to at
+// most two images, so slots are reserved with one atomic per (wave, image).
+__device__ __forceinline__ void emit_candidates_wave(const bool valid_row, const u64 best,
+                                                     const int j, const int n, const int N,
+                                                     const float4* __restrict__ anchors,
+                                                     const float* __restrict__ reg,
+                                                     const BoxCoder bc, const float width,
+                                                     const float height, const float thresh,
+                                                     const CandOut o) {
+  const int lane = threadIdx.x & 63;
   const float score = key_score(best);
-  if (!(score > thresh)) return;
+  const bool cand = valid_row && (score > thresh);
+  const int j_first = __builtin_amdgcn_readfirstlane(j);
+  u64 todo = __ballot(cand);
+  int slot = -1;
+  // at most two distinct images per wave: the first lane's, then whatever remains
+  for (int pass = 0; pass < 2 && todo; ++pass) {
+    const int jj = pass == 0 ? j_first : __builtin_amdgcn_readfirstlane(
+        __shfl(j, __builtin_ctzll(todo), 64));
+    const u64 grp = __ballot(cand && j == jj) & todo;
+    if (grp) {
+      int base = 0;
+      if (lane == __builtin_ctzll(grp))
+        base = atomicAdd(&o.cand_count[(size_t)jj * kCounterStride], __popcll(grp));
+      base = __shfl(base, __builtin_ctzll(grp), 64);
+      if (cand && j == jj) slot = base + __popcll(grp & ((1ull << lane) - 1ull));
+      todo &= ~grp;
+    }
+  }
+  if (!cand) return;
   const size_t row = (size_t)j * N + n;
   const float4 d = reinterpret_cast<const float4*>(reg)[row];
   o.dense_box[row] = clip_box(decode_box(anchors[n], d, bc), width, height);
   o.dense_label[row] = (int)key_index(best);
-  const int slot = atomicAdd(&o.cand_count[j], 1);
   if (slot < o.cap) {
     o.keys[(size_t)j * o.key_stride + slot] = make_key(score, (unsigned)n);
   } else {
-    atomicAdd(&o.overflow[j], 1);
+    atomicAdd(&o.overflow[(size_t)j * kCounterStride], 1);
   }
 }
 
@@ -140,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void decode_tile_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int v = v0 + u * kThreads;
-        if (v < nvec) val[u] = p4[v];
+        if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -175,10 +198,11 @@ __global__ __launch_bounds__(kThreads) void decode_tile_kernel(
       }
     }
     __syncthreads();
-    if (tid < rows) {
-      const int grow = row0 + tid;
+    if (tid < kTileRows) {     // wave 0: one lane per row
+      const int grow = min(row0 + tid, total_rows - 1);
       const int j = grow / N;
-      emit_candidate(s_best[tid], j, grow - j * N, N, anchors, reg, bc, width, height, thresh, o);
+      emit_candidates_wave(tid < rows, s_best[tid], j, grow - j * N, N, anchors, reg, bc, width,
+                           height, thresh, o);
     }
   }
 }
@@ -214,12 +238,23 @@ __global__ __launch_bounds__(kThreads) void decode_rows_kernel(
                                      reg[row * 4 + 3]);
         o.dense_box[row] = clip_box(decode_box(a, d, bc), width, height);
         o.dense_label[row] = (int)key_index(best);
-        const int slot = atomicAdd(&o.cand_count[j], 1);
+        const int slot = atomicAdd(&o.cand_count[(size_t)j * kCounterStride], 1);
         if (slot < o.cap) o.keys[(size_t)j * o.key_stride + slot] = make_key(score, (unsigned)n);
-        else atomicAdd(&o.overflow[j], 1);
+        else atomicAdd(&o.overflow[(size_t)j * kCounterStride], 1);
       }
     }
   }
+}
+
+// Per-image counters live one per 128-byte line; copy them out densely.
+__global__ __launch_bounds__(kThreads) void export_counters_kernel(const int* __restrict__ cnt,
+                                                                   const int* __restrict__ ovf,
+                                                                   int* __restrict__ cnt_out,
+                                                                   int* __restrict__ ovf_out, int B) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  if (j >= B) return;
+  if (cnt_out) cnt_out[j] = cnt[(size_t)j * kCounterStride];
+  if (ovf_out) ovf_out[j] = ovf[(size_t)j * kCounterStride];
 }
 
 // Keys for a plain (boxes, scores) NMS call: every box is a candidate.
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
   extern __shared__ __attribute__((aligned(16))) u64 s_keys[];
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
-  const int K = min(cand_count[j], cap);
+  const int K = min(cand_count[(size_t)j * kCounterStride], cap);
   const int P = next_pow2(max(K, 1));
   u64* kj = keys + (size_t)j * key_stride;
   for (int i = tid; i < P; i += kSortThreads) s_keys[i] = i < K ? kj[i] : 0ull;
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
   for (int i = tid; i < ke; i += kSortThreads)
     store_sorted(s_keys[i], i, j, N, kj, dense_box, dense_label, sbox + (size_t)j * box_stride,
                  slabel ? slabel + (size_t)j * box_stride : nullptr);
-  if (tid == 0) keff[j] = ke;
+  if (tid == 0) keff[(size_t)j * kCounterStride] = ke;
 }
 
 // Global-memory fallback for candidate lists that do not fit LDS.
@@ -295,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void sort_pad_kernel(u64* __restrict__ ke
                                                             int cap, int key_stride, int P) {
   const int j = blockIdx.y;
   const int i = blockIdx.x * kThreads + threadIdx.x;
-  const int K = min(cand_count[j], cap);
+  const int K = min(cand_count[(size_t)j * kCounterStride], cap);
   if (i < P && i >= K) keys[(size_t)j * key_stride + i] = 0ull;
 }
 __global__ __launch_bounds__(kThreads) void sort_step_kernel(u64* __restrict__ keys, int key_stride,
@@ -320,13 +355,13 @@ __global__ __launch_bounds__(kThreads) void sort_gather_kernel(
     int box_stride) {
   const int j = blockIdx.y;
   const int i = blockIdx.x * kThreads + threadIdx.x;
-  const int K = min(cand_count[j], cap);
+  const int K = min(cand_count[(size_t)j * kCounterStride], cap);
   const int ke = topk > 0 ? min(K, topk) : K;
   u64* kj = keys + (size_t)j * key_stride;
   if (i < ke)
     store_sorted(kj[i], i, j, N, kj, dense_box, dense_label, sbox + (size_t)j * box_stride,
                  slabel ? slabel + (size_t)j * box_stride : nullptr);
-  if (i == 0) keff[j] = ke;
+  if (i == 0) keff[(size_t)j * kCounterStride] = ke;
 }
 
 // ---------------------------------------------------------------------------
@@ -355,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __rest
   __shared__ int s_lab[kThreads / 64][64];
   const int j = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = keff[j];
+  const int K = keff[(size_t)j * kCounterStride];
   const int W = (K + 63) >> 6;
   const long long T = (long long)W * (W + 1) / 2;
   const float4* bj = sbox + (size_t)j * box_stride;
@@ -394,16 +429,19 @@ __global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __rest
       hit = hit && (ct * 64 + cc > i);
       bits |= hit ? (1ull << cc) : 0ull;
     }
-    if (i < K) mj[(size_t)i * wstride + ct] = bits;
+    // column-major: word (column tile ct, row i); a wave writes 512 contiguous bytes
+    if (i < K) mj[(size_t)ct * box_stride + i] = bits;
     __builtin_amdgcn_wave_barrier();
   }
 }
 
 // ---------------------------------------------------------------------------
-// Greedy sweep: one wave per image walks the sorted boxes in chunks of 64.  The
-// "removed" bitmap lives in LDS.  Per chunk: the diagonal mask words resolve which
-// of the chunk's live boxes are kept (one scalar step per kept box), then the kept
-// boxes' mask rows are OR-ed into the bitmap for all later chunks.
+// Greedy sweep: one wave per image walks the sorted boxes in chunks of 64.  For
+// chunk c the wave first PULLS the chunk's "removed" word: the OR, over the kept
+// boxes of all earlier chunks, of their mask word for column tile c (coalesced
+// reads of the column-major mask, lane-wise masked by the kept bitmap, one wave
+// OR-reduction).  The diagonal words then resolve the chunk itself: only rows that
+// overlap a later row of the same chunk need a serial step.
 // Outputs either the kept original indices (keep_idx, for rh_nms) or the
 // (score, label, box) triples of model.py:338-340.
 // ---------------------------------------------------------------------------
@@ -417,41 +455,60 @@ struct SweepOut {
   int max_keep;          // stop after this many (<= out_stride)
 };
 
+__device__ __forceinline__ u64 wave_or(u64 v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo |= (unsigned)__shfl_xor((int)lo, o, 64);
+    hi |= (unsigned)__shfl_xor((int)hi, o, 64);
+  }
+  return ((u64)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(64) void nms_sweep_kernel(const u64* __restrict__ keys,
                                                        const float4* __restrict__ sbox,
                                                        const int* __restrict__ slabel,
                                                        const int* __restrict__ keff,
                                                        const u64* __restrict__ mask, int key_stride,
                                                        int box_stride, int wstride, SweepOut o) {
-  extern __shared__ __attribute__((aligned(16))) u64 s_removed[];
+  extern __shared__ __attribute__((aligned(16))) u64 s_kept[];   // kept bitmap, one word per chunk
   const int j = blockIdx.x;
   const int lane = threadIdx.x;
-  const int K = keff[j];
+  const int K = keff[(size_t)j * kCounterStride];
   const int W = (K + 63) >> 6;
   const u64* kj = keys + (size_t)j * key_stride;
   const float4* bj = sbox + (size_t)j * box_stride;
   const int* lj = slabel ? slabel + (size_t)j * box_stride : nullptr;
   const u64* mj = mask + (size_t)j * box_stride * wstride;
-  for (int w = lane; w < W; w += 64) s_removed[w] = 0ull;
-  __syncthreads();
   int kept_total = 0;
   for (int c = 0; c < W && kept_total < o.max_keep; ++c) {
+    const u64* col = mj + (size_t)c * box_stride;
     const int row = c * 64 + lane;
     const bool valid = row < K;
-    const u64 diag = valid ? mj[(size_t)row * wstride + c] : 0ull;
+    const u64 diag = valid ? col[row] : 0ull;
+    // pull: which rows of this chunk were suppressed by boxes kept earlier
+    u64 acc = 0ull;
+#pragma unroll 8
+    for (int i = 0; i < c; ++i) {
+      const u64 word = col[i * 64 + lane];
+      acc |= ((s_kept[i] >> lane) & 1ull) ? word : 0ull;
+    }
+    const u64 removed = wave_or(acc);
     const u64 live_rows = (K - c * 64 >= 64) ? ~0ull : ((1ull << (K - c * 64)) - 1ull);
-    u64 alive = ~s_removed[c] & live_rows;
-    u64 kept = 0ull;
+    u64 alive = ~removed & live_rows;
+    // serial part: only rows that suppress something inside the chunk matter
+    u64 todo = __ballot(diag != 0ull) & alive;
     const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-    while (alive) {
-      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
-      kept |= 1ull << b;
+    while (todo) {
+      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
       const u64 d = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
                     (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-      alive &= ~(1ull << b);
-      alive &= ~d;
+      alive &= ~d;               // d only has bits above b
+      todo &= alive;
+      todo &= ~((2ull << b) - 1ull);
     }
-    // outputs of this chunk's kept boxes, in order
+    const u64 kept = alive;
+    if (lane == 0) s_kept[c] = kept;
     if ((kept >> lane) & 1ull) {
       const int pos = kept_total + __popcll(kept & ((1ull << lane) - 1ull));
       if (pos < o.max_keep) {
@@ -464,17 +521,7 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const u64* __restrict__ k
       }
     }
     kept_total += __popcll(kept);
-    // suppress later chunks
-    if (c + 1 < W) {
-      u64 rest = kept;
-      while (rest) {
-        const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
-        rest &= ~(1ull << b);
-        const u64* mrow = mj + (size_t)(c * 64 + b) * wstride;
-        for (int w = c + 1 + lane; w < W; w += 64) s_removed[w] |= mrow[w];
-      }
-    }
-    __syncthreads();
+    __syncthreads();   // s_kept[c] visible to the next chunk's pull
   }
   if (lane == 0) o.count[j] = min(kept_total, o.max_keep);
 }
@@ -627,7 +674,7 @@ struct PostWorkspace {
   u64* keys;
   float4* dense_box;
   int* dense_label;
-  int* counters;     // [3][B]: cand_count, overflow, keff  (zeroed each call)
+  int* counters;     // [3][B][kCounterStride]: cand_count, overflow, keff (zeroed each call)
   float4* sbox;
   int* slabel;
   u64* mask;
@@ -640,7 +687,7 @@ static PostWorkspace carve_post(void* ws, const NmsPlan& p, long long dense_rows
   w.keys = cv.take<u64>((size_t)p.batch * p.key_stride);
   w.dense_box = cv.take<float4>((size_t)dense_rows);
   w.dense_label = cv.take<int>((size_t)dense_rows);
-  w.counters = cv.take<int>((size_t)3 * p.batch);
+  w.counters = cv.take<int>((size_t)3 * p.batch * kCounterStride);
   w.sbox = cv.take<float4>((size_t)p.batch * p.box_cap);
   w.slabel = cv.take<int>((size_t)p.batch * p.box_cap);
   w.mask = cv.take<u64>((size_t)p.batch * p.box_cap * p.wstride);
@@ -709,7 +756,7 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
   const PostWorkspace w = carve_post(workspace, p, 0);
   int* cand_count = w.counters;
-  int* keff = w.counters + 2;
+  int* keff = w.counters + 2 * kCounterStride;
   hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((k + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, scores, w.keys, (int)k, cand_count);
   RH_CHECK_LAUNCH("make_keys_kernel");
@@ -765,12 +812,12 @@ int rh_postprocess(const float* classifications, const float* regressions, const
   hipStream_t s = (hipStream_t)stream;
   const PostWorkspace w = carve_post(workspace, p, (long long)batch * n);
   int* cnt = w.counters;
-  int* ovf = w.counters + batch;
-  int* keff = w.counters + 2 * batch;
+  int* ovf = w.counters + (size_t)batch * kCounterStride;
+  int* keff = w.counters + (size_t)2 * batch * kCounterStride;
   const int out_cap = q->max_det > 0 ? q->max_det : p.box_cap;
 
   if (stages & RH_POST_DECODE) {
-    RH_CHECK_HIP(hipMemsetAsync(w.counters, 0, sizeof(int) * 3 * batch, s));
+    RH_CHECK_HIP(hipMemsetAsync(w.counters, 0, sizeof(int) * 3 * batch * kCounterStride, s));
     CandOut co{w.keys, w.dense_box, w.dense_label, cnt, ovf, p.cap, p.key_stride};
     const BoxCoder bc = make_coder(nullptr, nullptr);
     const int total_rows = (int)((long long)batch * n);
@@ -778,8 +825,9 @@ int rh_postprocess(const float* classifications, const float* regressions, const
                       aligned16(classifications);
     if (tile) {
       const int num_tiles = (total_rows + kTileRows - 1) / kTileRows;
-      const int grid = num_tiles < 256 * 8 ? num_tiles : 256 * 8;
-      hipLaunchKernelGGL(decode_tile_kernel<4>, dim3(grid), dim3(kThreads), 0, s, classifications,
+      const bool u5 = ((kTileRows * num_classes / 4 + kThreads - 1) / kThreads) % 5 == 0;
+      auto kern = u5 ? decode_tile_kernel<5> : decode_tile_kernel<4>;
+      hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications,
                          regressions, reinterpret_cast<const float4*>(anchors), co, (int)n,
                          num_classes, total_rows, num_tiles, div_magic((unsigned)num_classes), bc,
                          q->width, q->height, q->score_thresh);
@@ -809,10 +857,11 @@ int rh_postprocess(const float* classifications, const float* regressions, const
     if (int e = launch_nms(p, w.keys, w.sbox, w.slabel, keff, w.mask, q->iou_thresh, q->per_class,
                            out, s))
       return e;
-    if (cand_count)
-      RH_CHECK_HIP(hipMemcpyAsync(cand_count, cnt, sizeof(int) * batch, hipMemcpyDeviceToDevice, s));
-    if (overflow)
-      RH_CHECK_HIP(hipMemcpyAsync(overflow, ovf, sizeof(int) * batch, hipMemcpyDeviceToDevice, s));
+    if (cand_count || overflow) {
+      hipLaunchKernelGGL(export_counters_kernel, dim3((batch + kThreads - 1) / kThreads),
+                         dim3(kThreads), 0, s, cnt, ovf, cand_count, overflow, batch);
+      RH_CHECK_LAUNCH("export_counters_kernel");
+    }
   }
   return RH_OK;
 }

@@ -8,6 +8,7 @@
 // Everything is HBM-bound float32 streaming; there is no contraction, so no MFMA.
 // The file is compiled with -ffp-contract=off: IoU values feed thresholds and an
 // arg-max whose integer results must equal the reference's bit for bit.
+#include <stdlib.h>
 #include "rh_common.h"
 
 namespace rh {
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict_
   const float* a = ann + (size_t)j * M * 5;
   GtRec* out = gt + (size_t)j * M;
   int base = 0;
+  int bad = 0;
   for (int m0 = 0; m0 < M; m0 += 64) {
     const int m = m0 + lane;
     float lab = -1.0f;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict_
       int l = (int)lab;
       if (!(lab > -1.0f && lab < (float)C)) {   // also catches NaN
         l = -1;
-        if (status) atomicOr(status, RH_STATUS_LABEL_RANGE);
+        bad = 1;
       }
       r.label = l;
       r.pad0 = r.pad1 = 0;
@@ -75,34 +77,39 @@ __global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict_
     }
     base += __popcll(mask);
   }
+  const unsigned long long any_bad = __ballot(bad != 0);
   if (lane == 0) {
     gt_count[j] = base;
     num_pos[j] = 0;
+    if (status) status[j] = any_bad ? RH_STATUS_LABEL_RANGE : 0;
   }
 }
 
 // ---------------------------------------------------------------------------
 // IoU of one anchor with one GT, float32, operation order of losses.py:9-21.
-// Returns 0 without dividing when the boxes do not overlap (0 / ua == 0 exactly).
+// Returns 0 without dividing when the boxes do not overlap: the reference clamps
+// iw and ih at 0, so its intersection is 0 and 0 / ua == 0 exactly.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, const float4 b,
                                           const float area_b) {
-  float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x);
-  float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
-  iw = fmaxf(iw, 0.0f);
-  ih = fmaxf(ih, 0.0f);
+  const float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x);
+  const float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+  if (!(fminf(iw, ih) > 0.0f)) return 0.0f;
   const float inter = iw * ih;
-  if (!(inter > 0.0f)) return 0.0f;
   float ua = (area_a + area_b) - inter;
   ua = fmaxf(ua, 1e-8f);
   return inter / ua;
 }
 
 // ---------------------------------------------------------------------------
-// Assignment: one thread per (image, anchor); the image's GT boxes are staged
-// through LDS in chunks and read as wave-uniform broadcasts.  Max / first arg-max
-// (losses.py:61), thresholds (:70-72), label lookup (:76-79), positive count (:74).
+// Assignment: kAssignPer anchors per thread (strided by the block size, so loads
+// and stores stay coalesced); the image's GT boxes are staged through LDS in
+// chunks and read as wave-uniform broadcasts, once for all of a thread's anchors.
+// Max / first arg-max (losses.py:61), thresholds (:70-72), label lookup (:76-79),
+// positive count (:74).
 // ---------------------------------------------------------------------------
+constexpr int kAssignPer = 4;
+
 __global__ __launch_bounds__(kThreads) void assign_kernel(
     const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ gt_count, int* __restrict__ code, unsigned char* __restrict__ state,
@@ -113,16 +120,21 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
   __shared__ int s_pos[kThreads / 64];
 
   const int j = blockIdx.y;
-  const int n = blockIdx.x * kThreads + threadIdx.x;
+  const int base = blockIdx.x * (kThreads * kAssignPer) + threadIdx.x;
   const int cnt = gt_count[j];
   const GtRec* g = gt + (size_t)j * M;
 
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n < N) a = anchors[n];
-  const float area_a = (a.z - a.x) * (a.w - a.y);
-
-  float best = 0.0f;   // every IoU is >= 0, so "first maximum" starts at (0, index 0)
-  int best_idx = 0;
+  float4 a[kAssignPer];
+  float area_a[kAssignPer], best[kAssignPer];
+  int best_idx[kAssignPer];
+#pragma unroll
+  for (int k = 0; k < kAssignPer; ++k) {
+    const int n = base + k * kThreads;
+    a[k] = n < N ? anchors[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+    area_a[k] = (a[k].z - a[k].x) * (a[k].w - a[k].y);
+    best[k] = 0.0f;   // every IoU is >= 0, so "first maximum" starts at (0, index 0)
+    best_idx[k] = 0;
+  }
   for (int c0 = 0; c0 < cnt; c0 += kGtChunk) {
     const int len = min(kGtChunk, cnt - c0);
     __syncthreads();
@@ -132,42 +144,69 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
       s_area[i] = r.area;
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll 2
     for (int i = 0; i < len; ++i) {
-      const float v = iou_pair(a, area_a, s_box[i], s_area[i]);
-      if (v > best) {
-        best = v;
-        best_idx = c0 + i;
+      const float4 b = s_box[i];
+      // overlap test for the thread's anchors first; one (rare) branch per GT box
+      float iw[kAssignPer], ih[kAssignPer], m[kAssignPer];
+#pragma unroll
+      for (int k = 0; k < kAssignPer; ++k) {
+        iw[k] = fminf(a[k].z, b.z) - fmaxf(a[k].x, b.x);
+        ih[k] = fminf(a[k].w, b.w) - fmaxf(a[k].y, b.y);
+        m[k] = fminf(iw[k], ih[k]);
+      }
+      float any = m[0];
+#pragma unroll
+      for (int k = 1; k < kAssignPer; ++k) any = fmaxf(any, m[k]);
+      if (any > 0.0f) {
+        const float ab = s_area[i];
+#pragma unroll
+        for (int k = 0; k < kAssignPer; ++k) {
+          // losses.py:12-21; a non-positive iw or ih clamps the intersection, hence the IoU, to 0
+          const float inter = iw[k] * ih[k];
+          float ua = (area_a[k] + ab) - inter;
+          ua = fmaxf(ua, 1e-8f);
+          const float v = m[k] > 0.0f ? inter / ua : 0.0f;
+          if (v > best[k]) {
+            best[k] = v;
+            best_idx[k] = c0 + i;
+          }
+        }
       }
     }
   }
 
-  int st, cd, lb = -1;
-  if (cnt == 0) {
-    st = RH_IGNORE;      // losses.py:51-55: the image contributes nothing
-    cd = kCodeIgn;
-  } else if (best >= pos_thresh) {
-    st = RH_POSITIVE;
-    lb = g[best_idx].label;
-    cd = (best_idx << 16) | (lb < 0 ? kNoLabel : lb);
-  } else if (best < neg_thresh) {
-    st = RH_NEGATIVE;
-    cd = kCodeNeg;
-  } else {
-    st = RH_IGNORE;
-    cd = kCodeIgn;
+  int npos = 0;
+#pragma unroll
+  for (int k = 0; k < kAssignPer; ++k) {
+    const int n = base + k * kThreads;
+    int st, cd, lb = -1;
+    if (cnt == 0) {
+      st = RH_IGNORE;      // losses.py:51-55: the image contributes nothing
+      cd = kCodeIgn;
+    } else if (best[k] >= pos_thresh) {
+      st = RH_POSITIVE;
+      lb = g[best_idx[k]].label;
+      cd = (best_idx[k] << 16) | (lb < 0 ? kNoLabel : lb);
+    } else if (best[k] < neg_thresh) {
+      st = RH_NEGATIVE;
+      cd = kCodeNeg;
+    } else {
+      st = RH_IGNORE;
+      cd = kCodeIgn;
+    }
+    if (n < N) {
+      const size_t o = (size_t)j * N + n;
+      if (code) code[o] = cd;
+      if (state) state[o] = (unsigned char)st;
+      if (argmax) argmax[o] = best_idx[k];
+      if (label) label[o] = lb;
+      if (iou_max) iou_max[o] = best[k];
+      npos += st == RH_POSITIVE;
+    }
   }
-  const bool in = n < N;
-  if (in) {
-    const size_t o = (size_t)j * N + n;
-    if (code) code[o] = cd;
-    if (state) state[o] = (unsigned char)st;
-    if (argmax) argmax[o] = best_idx;
-    if (label) label[o] = lb;
-    if (iou_max) iou_max[o] = best;
-  }
-  const unsigned long long pm = __ballot(in && st == RH_POSITIVE);
-  if ((threadIdx.x & 63) == 0) s_pos[threadIdx.x >> 6] = __popcll(pm);
+  npos = wave_sum(npos);
+  if ((threadIdx.x & 63) == 0) s_pos[threadIdx.x >> 6] = npos;
   __syncthreads();
   if (threadIdx.x == 0) {
     int t = 0;
@@ -284,7 +323,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // Requirements checked on the host: 4 <= C < 8192, N >= 64, all pointers 16-byte
 // aligned, B*N < 2^31.
 // ---------------------------------------------------------------------------
-template <int U>
+template <int U, bool NTL, bool NTS>
 __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
@@ -356,7 +395,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
+          if (v < nvec) val[u] = NTL ? __builtin_nontemporal_load(&p4[v]) : p4[v];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -369,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
             cl0 += focal_zero(val[u].w, fc, k0l, k0g, g3);
             v4f o;
             o.x = g0; o.y = g1; o.z = g2; o.w = g3;
-            __builtin_nontemporal_store(o, &d4[v]);
+            if (NTS) __builtin_nontemporal_store(o, &d4[v]); else d4[v] = o;
           }
         }
       }
@@ -379,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
+          if (v < nvec) val[u] = NTL ? __builtin_nontemporal_load(&p4[v]) : p4[v];
         }
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
@@ -411,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
             }
             v4f o;
             o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
-            __builtin_nontemporal_store(o, &d4[v]);
+            if (NTS) __builtin_nontemporal_store(o, &d4[v]); else d4[v] = o;
           }
         }
       }
@@ -503,82 +542,84 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Final reductions (fixed order, double accumulation).
-// finalize_images: one block per image; sums the image's partials, applies the
-// normalisers of losses.py:94 and :134.  tile_mode: partials are the tile
-// kernel's [tile][4] records, else the generic kernel's [B][blocks][2].
+// Final reduction, one workgroup of 16 waves, fixed order, double accumulation.
+// Wave w sums the partials of images w, w+16, ... (lane-strided, then a butterfly)
+// and applies the normalisers of losses.py:94 and :134; wave 0 then forms the batch
+// means of losses.py:139-141.  tile_mode: partials are the tile kernel's [tile][4]
+// records, else the generic kernel's [B][blocks][2].
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void finalize_images_kernel(
+constexpr int kFinalThreads = 1024;
+
+__global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     const float* __restrict__ partials, const int* __restrict__ num_pos,
     const int* __restrict__ gt_count, float* __restrict__ per_image, int* __restrict__ num_pos_out,
-    int B, int N, int tile_mode, int generic_blocks) {
-  __shared__ double s_c[kThreads / 64], s_r[kThreads / 64];
-  const int j = blockIdx.x;
-  double c = 0.0, r = 0.0;
-  if (tile_mode) {
-    const long long first = (long long)j * N, last = first + N - 1;
-    const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
-    for (int t = t_lo + threadIdx.x; t <= t_hi; t += kThreads) {
-      const int slot = j - (int)(((long long)t * kTileRows) / N);   // 0 or 1
-      const float4 q = reinterpret_cast<const float4*>(partials)[t];
-      c += slot ? q.y : q.x;
-      r += slot ? q.w : q.z;
+    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < B; j += kFinalThreads / 64) {
+    double c = 0.0, r = 0.0;
+    if (tile_mode) {
+      const long long first = (long long)j * N, last = first + N - 1;
+      const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
+      for (int t = t_lo + lane; t <= t_hi; t += 64) {
+        const int slot = j - (int)(((long long)t * kTileRows) / N);   // 0 or 1
+        const float4 q = reinterpret_cast<const float4*>(partials)[t];
+        c += slot ? q.y : q.x;
+        r += slot ? q.w : q.z;
+      }
+    } else {
+      for (int t = lane; t < generic_blocks; t += 64) {
+        c += partials[((size_t)j * generic_blocks + t) * 2];
+        r += partials[((size_t)j * generic_blocks + t) * 2 + 1];
+      }
     }
-  } else {
-    for (int t = threadIdx.x; t < generic_blocks; t += kThreads) {
-      c += partials[((size_t)j * generic_blocks + t) * 2];
-      r += partials[((size_t)j * generic_blocks + t) * 2 + 1];
+    c = wave_sum(c);
+    r = wave_sum(r);
+    if (lane == 0) {
+      const int np = num_pos[j];
+      const bool empty = gt_count[j] == 0;
+      per_image[j] = empty ? 0.f : (float)c / (float)max(np, 1);
+      per_image[B + j] = (empty || np == 0) ? 0.f : (float)r / (4.0f * (float)np);
+      if (num_pos_out) num_pos_out[j] = np;
     }
   }
-  c = wave_sum(c);
-  r = wave_sum(r);
-  if ((threadIdx.x & 63) == 0) {
-    s_c[threadIdx.x >> 6] = c;
-    s_r[threadIdx.x >> 6] = r;
-  }
+  __threadfence_block();
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double cs = 0.0, rs = 0.0;
-#pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) {
-      cs += s_c[w];
-      rs += s_r[w];
+  if (wave == 0) {
+    double c = 0.0, r = 0.0;
+    for (int j = lane; j < B; j += 64) {
+      c += per_image[j];
+      r += per_image[B + j];
     }
-    const int np = num_pos[j];
-    const bool empty = gt_count[j] == 0;
-    per_image[j] = empty ? 0.f : (float)cs / (float)max(np, 1);
-    per_image[B + j] = (empty || np == 0) ? 0.f : (float)rs / (4.0f * (float)np);
-    if (num_pos_out) num_pos_out[j] = np;
+    c = wave_sum(c);
+    r = wave_sum(r);
+    if (lane == 0) {
+      losses[0] = (float)(c / (double)divisor);
+      losses[1] = (float)(r / (double)divisor);
+    }
   }
 }
 
-// Batch means (losses.py:139-141): one wave, lane-strided then a fixed butterfly.
-__global__ __launch_bounds__(64) void finalize_batch_kernel(const float* __restrict__ per_image,
-                                                            float* __restrict__ losses, int B,
-                                                            float divisor) {
-  double c = 0.0, r = 0.0;
-  for (int j = threadIdx.x; j < B; j += 64) {
-    c += per_image[j];
-    r += per_image[B + j];
-  }
-  c = wave_sum(c);
-  r = wave_sum(r);
-  if (threadIdx.x == 0) {
-    losses[0] = (float)(c / (double)divisor);
-    losses[1] = (float)(r / (double)divisor);
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void scale_inplace_kernel(float* __restrict__ x,
-                                                                 long long count,
-                                                                 const float* __restrict__ scale,
-                                                                 float assumed) {
-  const float s = *scale;
-  if (s == assumed) return;          // uniform: the whole grid leaves without traffic
-  const float f = s / assumed;
+// x *= (*sx) / assumed and y *= (*sy) / assumed in one launch; each array is left alone
+// (no traffic) when its scale equals `assumed`.  A null scale pointer means "zero the array".
+__global__ __launch_bounds__(kThreads) void apply_upstream_kernel(
+    float* __restrict__ x, long long nx, const float* __restrict__ sx, float* __restrict__ y,
+    long long ny, const float* __restrict__ sy, float assumed) {
   const long long stride = (long long)gridDim.x * kThreads;
-  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride)
-    x[i] *= f;
+  const long long t0 = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (x) {
+    const float s = sx ? *sx : 0.0f;
+    if (s != assumed) {
+      const float f = s / assumed;
+      for (long long i = t0; i < nx; i += stride) x[i] = sx ? x[i] * f : 0.0f;
+    }
+  }
+  if (y) {
+    const float s = sy ? *sy : 0.0f;
+    if (s != assumed) {
+      const float f = s / assumed;
+      for (long long i = t0; i < ny; i += stride) y[i] = sy ? y[i] * f : 0.0f;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -633,7 +674,8 @@ static int launch_assign(const float* anchors, const float* annotations, int bat
   hipLaunchKernelGGL(gt_prepare_kernel, dim3(batch), dim3(64), 0, s, annotations, w.gt, w.gt_count,
                      w.num_pos, status, m, c);
   RH_CHECK_LAUNCH("gt_prepare_kernel");
-  dim3 grid((unsigned)((n + kThreads - 1) / kThreads), (unsigned)batch);
+  const int per_block = kThreads * kAssignPer;
+  dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)batch);
   hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
                      reinterpret_cast<const float4*>(anchors), w.gt, w.gt_count, code, state, argmax,
                      label, iou_max, w.num_pos, (int)n, m, neg_t, pos_t);
@@ -732,12 +774,30 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   }
   if (stages & RH_STAGE_STREAM) {
     if (tile) {
-      const int grid = num_tiles < 256 * 8 ? num_tiles : 256 * 8;
       // float4 slots per thread and tile: pick the unroll that wastes the fewest
       const int per_thread = (kTileRows * num_classes / 4 + kThreads - 1) / kThreads;
       const bool u5 = (per_thread + 4) / 5 * 5 < (per_thread + 3) / 4 * 4;
-      auto kern = u5 ? focal_stream_kernel<5> : focal_stream_kernel<4>;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), 0, s, classifications,
+      // tuning knobs (experiments only)
+      const char* eg = getenv("RH_STREAM_GRID");
+      const char* ev = getenv("RH_STREAM_VARIANT");
+      int grid2 = eg ? atoi(eg) : num_tiles;
+      if (grid2 <= 0 || grid2 > num_tiles) grid2 = num_tiles;
+      const int var = ev ? atoi(ev) : 3;
+      void (*kern)(const float*, float*, const float*, float*, const float4*, const GtRec*,
+                   const int*, const int*, float*, int, int, int, int, int, unsigned, FocalConst,
+                   float, float, float);
+      if (u5) {
+        kern = var == 0 ? focal_stream_kernel<5, false, false>
+             : var == 1 ? focal_stream_kernel<5, true, false>
+             : var == 2 ? focal_stream_kernel<5, false, true>
+                        : focal_stream_kernel<5, true, true>;
+      } else {
+        kern = var == 0 ? focal_stream_kernel<4, false, false>
+             : var == 1 ? focal_stream_kernel<4, true, false>
+             : var == 2 ? focal_stream_kernel<4, false, true>
+                        : focal_stream_kernel<4, true, true>;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid2), dim3(kThreads), 0, s, classifications,
                          d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.num_pos,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
@@ -754,27 +814,28 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   }
   if (stages & RH_STAGE_FINALIZE) {
     float* pi = per_image ? per_image : w.per_image;
-    hipLaunchKernelGGL(finalize_images_kernel, dim3(batch), dim3(kThreads), 0, s, w.partials,
-                       w.num_pos, w.gt_count, pi, num_pos, batch, (int)n, tile ? 1 : 0,
-                       kGenericBlocks);
-    RH_CHECK_LAUNCH("finalize_images_kernel");
-    hipLaunchKernelGGL(finalize_batch_kernel, dim3(1), dim3(64), 0, s, pi, losses, batch, divisor);
-    RH_CHECK_LAUNCH("finalize_batch_kernel");
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.num_pos,
+                       w.gt_count, pi, num_pos, losses, batch, (int)n, tile ? 1 : 0, kGenericBlocks,
+                       divisor);
+    RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;
 }
 
-int rh_scale_inplace_f32(float* x, int64_t count, const float* scale_dev, float assumed,
-                         rh_stream_t stream) {
-  RH_REQUIRE(count >= 0, RH_ESHAPE, "count < 0");
-  if (count == 0) return RH_OK;
-  RH_REQUIRE(x && scale_dev, RH_EINVAL, "null pointer");
+int rh_apply_upstream_f32(float* x, int64_t nx, const float* scale_x, float* y, int64_t ny,
+                          const float* scale_y, float assumed, rh_stream_t stream) {
+  RH_REQUIRE(nx >= 0 && ny >= 0, RH_ESHAPE, "negative count");
   RH_REQUIRE(assumed != 0.0f, RH_EINVAL, "assumed scale must be non-zero");
-  long long blocks = (count + kThreads - 1) / kThreads;
+  if (nx == 0) x = nullptr;
+  if (ny == 0) y = nullptr;
+  if (!x && !y) return RH_OK;
+  const long long most = nx > ny ? nx : ny;
+  long long blocks = (most + kThreads - 1) / kThreads;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, (long long)count, scale_dev, assumed);
-  RH_CHECK_LAUNCH("scale_inplace_kernel");
+  hipLaunchKernelGGL(apply_upstream_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, (long long)nx, scale_x, y, (long long)ny, scale_y,
+                     assumed);
+  RH_CHECK_LAUNCH("apply_upstream_kernel");
   return RH_OK;
 }
 

@@ -74,7 +74,7 @@ SIGNATURES = {
     "rh_focal_loss_workspace_bytes": (_SZ, [_I32, _I64, _I32, _I32]),
     "rh_focal_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I32, _I32, C.POINTER(FocalParams),
                                         _P, _P, _P, _P, _P, _P, _P, _SZ, _I32, _P]),
-    "rh_scale_inplace_f32": (C.c_int, [_P, _I64, _P, _F, _P]),
+    "rh_apply_upstream_f32": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _F, _P]),
     "rh_generic_focal_workspace_bytes": (_SZ, [_I64]),
     "rh_generic_focal_fwd_bwd": (C.c_int, [_P, _P, _I64, _F, _F, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
     "rh_bbox_transform_f32": (C.c_int, [_P, _P, _I32, _I64, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),

@@ -50,9 +50,32 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def workspace(dev, nbytes, tag="default"):
+class _on_device:
+    """``with _on_device(dev) as stream:`` makes dev current only when it is not already (the
+    common single-GPU-per-process case costs one integer compare) and yields the raw stream."""
+    __slots__ = ("dev", "guard")
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.guard = None
+
+    def __enter__(self):
+        if torch.cuda.current_device() != self.dev.index:
+            self.guard = torch.cuda.device(self.dev)
+            self.guard.__enter__()
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
+def workspace(dev, nbytes, tag="default", stream=None):
     """A cached byte buffer per (device, stream, tag); grows, never shrinks."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
@@ -152,7 +175,7 @@ def assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5):
     label = torch.empty((bsz, n), dtype=torch.int32, device=dev)
     iou_max = torch.empty((bsz, n), dtype=torch.float32, device=dev)
     num_pos = torch.empty((bsz,), dtype=torch.int32, device=dev)
-    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    status = torch.empty((bsz,), dtype=torch.int32, device=dev)
     need = lib.rh_assign_workspace_bytes(bsz, n, m)
     ws = workspace(dev, need, "assign")
     with torch.cuda.device(dev):
@@ -165,11 +188,14 @@ def assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5):
 
 
 # --------------------------------------------------------------------------- fused loss
+_ws_bytes_cache = {}
+
+
 def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alpha=0.25,
                        neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
                        batch_divisor=0, stages=_lib.STAGE_ALL, out=None):
     """Runs the fused loss kernels.  Returns a dict of device tensors:
-    losses [2], per_image [2,B], num_pos [B], status [1], d_classifications, d_regressions.
+    losses [2], per_image [2,B], num_pos [B], status [B], d_classifications, d_regressions.
     ``out`` may carry buffers from an earlier call (used when stages are run one at a time).
     """
     dev = _dev_check(classifications, regressions, anchors_t, annotations)
@@ -185,37 +211,49 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     m = ann.shape[1]
     lib = _lib.load()
     if out is None:
+        # one small allocation for all scalar-ish outputs: [losses 2 | per_image 2B | num_pos B | status B]
+        small = torch.empty((2 + 4 * bsz,), dtype=torch.float32, device=dev)
         out = dict(
-            losses=torch.empty((2,), dtype=torch.float32, device=dev),
-            per_image=torch.empty((2, bsz), dtype=torch.float32, device=dev),
-            num_pos=torch.empty((bsz,), dtype=torch.int32, device=dev),
-            status=torch.zeros((1,), dtype=torch.int32, device=dev),
+            losses=small[0:2],
+            per_image=small[2:2 + 2 * bsz].view(2, bsz),
+            num_pos=small[2 + 2 * bsz:2 + 3 * bsz].view(torch.int32),
+            status=small[2 + 3 * bsz:].view(torch.int32),
             d_classifications=torch.empty_like(cls),
             d_regressions=torch.empty_like(reg),
         )
     params = _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
                               float(grad_reg), int(batch_divisor))
-    need = lib.rh_focal_loss_workspace_bytes(bsz, n, c, m)
-    ws = workspace(dev, need, "focal")
-    with torch.cuda.device(dev):
+    shape_key = (bsz, n, c, m)
+    need = _ws_bytes_cache.get(shape_key)
+    if need is None:
+        need = _ws_bytes_cache[shape_key] = lib.rh_focal_loss_workspace_bytes(bsz, n, c, m)
+    with _on_device(dev) as stream:
+        ws = workspace(dev, need, "focal", stream)
         _lib.check(lib.rh_focal_loss_fwd_bwd(
-            _p(cls), _p(reg), _p(anc), _p(ann), bsz, n, c, m, C.byref(params),
-            _p(out["d_classifications"]), _p(out["d_regressions"]), _p(out["losses"]),
-            _p(out["per_image"]), _p(out["num_pos"]), _p(out["status"]), _p(ws), ws.numel(),
-            int(stages), _stream(dev)), "rh_focal_loss_fwd_bwd")
+            cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), bsz, n, c, m,
+            C.byref(params), out["d_classifications"].data_ptr(), out["d_regressions"].data_ptr(),
+            out["losses"].data_ptr(), out["per_image"].data_ptr(), out["num_pos"].data_ptr(),
+            out["status"].data_ptr(), ws.data_ptr(), ws.numel(), int(stages), stream),
+            "rh_focal_loss_fwd_bwd")
     return out
 
 
-def scale_inplace(x, scale, assumed=1.0):
-    """x *= scale / assumed on the device, skipped (no traffic) when scale == assumed."""
-    dev = _dev_check(x, scale)
-    if not x.is_contiguous() or x.dtype != torch.float32:
-        raise RetinaHeadError("scale_inplace needs a contiguous float32 tensor")
-    s = _f32c(scale.reshape(-1)[:1])
-    with torch.cuda.device(dev):
-        _lib.check(_lib.load().rh_scale_inplace_f32(_p(x), x.numel(), _p(s), float(assumed),
-                                                    _stream(dev)), "rh_scale_inplace_f32")
-    return x
+def apply_upstream(d_cls, g_cls, d_reg, g_reg, assumed=1.0):
+    """In place and without a host read: d_cls *= g_cls/assumed, d_reg *= g_reg/assumed (one
+    launch; an array whose scale equals ``assumed`` is not touched).  A ``None`` gradient zeroes
+    its array, a ``None`` array is skipped."""
+    dev = _dev_check(d_cls, g_cls, d_reg, g_reg)
+    for t in (d_cls, d_reg):
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32):
+            raise RetinaHeadError("apply_upstream needs contiguous float32 tensors")
+    gc = None if g_cls is None else _f32c(g_cls.reshape(-1)[:1])
+    gr = None if g_reg is None else _f32c(g_reg.reshape(-1)[:1])
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    with _on_device(dev) as stream:
+        _lib.check(_lib.load().rh_apply_upstream_f32(
+            ptr(d_cls), 0 if d_cls is None else d_cls.numel(), ptr(gc),
+            ptr(d_reg), 0 if d_reg is None else d_reg.numel(), ptr(gr), float(assumed), stream),
+            "rh_apply_upstream_f32")
 
 
 def generic_focal_fwd_bwd(inputs, targets, alpha=0.25, gamma=2.0, logits=True, reduce=True):

@@ -22,7 +22,7 @@ def calc_iou(a, b):
 
 class _DenseHeadLossFn(torch.autograd.Function):
     """Forward launches the fused forward+backward kernels and keeps the gradients;
-    backward applies the upstream gradients to them in place (no host read)."""
+    backward applies the upstream gradients to them in place (one launch, no host read)."""
 
     @staticmethod
     def forward(ctx, classifications, regressions, anchors, annotations, cfg):
@@ -35,9 +35,11 @@ class _DenseHeadLossFn(torch.autograd.Function):
         ctx.d_reg = out["d_regressions"]
         ctx.expected = cfg["expected_grad"]
         ctx.in_dtypes = (classifications.dtype, regressions.dtype)
-        cfg["last"] = out
-        losses = out["losses"]
-        return losses[0:1].clone(), losses[1:2].clone()
+        # keep only the small outputs: a second reference to the gradient buffers would make
+        # autograd's AccumulateGrad copy them (hundreds of MB) instead of adopting them
+        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
+        losses = out["losses"]          # fresh storage every call: views need no copy
+        return losses[0:1], losses[1:2]
 
     @staticmethod
     def backward(ctx, g_cls, g_reg):
@@ -47,19 +49,10 @@ class _DenseHeadLossFn(torch.autograd.Function):
         d_cls, d_reg = ctx.d_cls, ctx.d_reg
         ctx.d_cls = ctx.d_reg = None
         need = ctx.needs_input_grad
-        out_cls = out_reg = None
-        if need[0]:
-            if g_cls is None:
-                out_cls = torch.zeros_like(d_cls)
-            else:
-                out_cls = F.scale_inplace(d_cls, g_cls, ctx.expected)
-            out_cls = out_cls.to(ctx.in_dtypes[0])
-        if need[1]:
-            if g_reg is None:
-                out_reg = torch.zeros_like(d_reg)
-            else:
-                out_reg = F.scale_inplace(d_reg, g_reg, ctx.expected)
-            out_reg = out_reg.to(ctx.in_dtypes[1])
+        F.apply_upstream(d_cls if need[0] else None, g_cls, d_reg if need[1] else None, g_reg,
+                         ctx.expected)
+        out_cls = d_cls.to(ctx.in_dtypes[0]) if need[0] else None
+        out_reg = d_reg.to(ctx.in_dtypes[1]) if need[1] else None
         return out_cls, out_reg, None, None, None
 
 
@@ -94,14 +87,14 @@ class FocalLoss(nn.Module):
 
     @property
     def last(self):
-        """Device tensors of the latest call: per_image [2,B], num_pos [B], status [1]."""
+        """Device tensors of the latest call: per_image [2,B], num_pos [B], status [B]."""
         return self.cfg["last"]
 
     def forward(self, classifications, regressions, anchors, annotations):
         cls_loss, reg_loss = _DenseHeadLossFn.apply(classifications, regressions, anchors,
                                                     annotations, self.cfg)
         if self.check_labels:
-            if int(self.cfg["last"]["status"].item()) & _lib.RH_STATUS_LABEL_RANGE:
+            if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
                 raise IndexError("annotation label outside [0, num_classes)")
         return {"classification_loss": cls_loss, "regression_loss": reg_loss}
 
