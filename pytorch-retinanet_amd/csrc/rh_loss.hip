@@ -35,6 +35,8 @@ constexpr int kTileRows = 64;      // anchors per stream tile
 constexpr int kThreads = 256;
 constexpr int kGtChunk = 256;      // GT boxes staged in LDS at a time
 constexpr int kGenericBlocks = 64; // blocks per image of the generic row kernel
+constexpr int kPosStride = 32;     // ints between per-image positive counters: one 128-byte line
+                                   // each, so the blocks' atomic adds do not queue on one line
 
 // ---------------------------------------------------------------------------
 // GT compaction: keeps rows with label != -1 in order (losses.py:48-49), stores
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict_
                                                         GtRec* __restrict__ gt,
                                                         int* __restrict__ gt_count,
                                                         int* __restrict__ num_pos,
-                                                        int* __restrict__ status, int M, int C) {
+                                                        int* __restrict__ status, int M, int C,
+                                                        int pos_stride) {
   const int j = blockIdx.x;
   const int lane = threadIdx.x;
   const float* a = ann + (size_t)j * M * 5;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict_
   const unsigned long long any_bad = __ballot(bad != 0);
   if (lane == 0) {
     gt_count[j] = base;
-    num_pos[j] = 0;
+    num_pos[(size_t)j * pos_stride] = 0;
     if (status) status[j] = any_bad ? RH_STATUS_LABEL_RANGE : 0;
   }
 }
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ gt_count, int* __restrict__ code, unsigned char* __restrict__ state,
     int* __restrict__ argmax, int* __restrict__ label, float* __restrict__ iou_max,
-    int* __restrict__ num_pos, int N, int M, float neg_thresh, float pos_thresh) {
+    int* __restrict__ num_pos, int N, int M, float neg_thresh, float pos_thresh, int pos_stride) {
   __shared__ float4 s_box[kGtChunk];
   __shared__ float s_area[kGtChunk];
   __shared__ int s_pos[kThreads / 64];
@@ -162,14 +165,20 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
         const float ab = s_area[i];
 #pragma unroll
         for (int k = 0; k < kAssignPer; ++k) {
-          // losses.py:12-21; a non-positive iw or ih clamps the intersection, hence the IoU, to 0
-          const float inter = iw[k] * ih[k];
-          float ua = (area_a[k] + ab) - inter;
-          ua = fmaxf(ua, 1e-8f);
-          const float v = m[k] > 0.0f ? inter / ua : 0.0f;
-          if (v > best[k]) {
-            best[k] = v;
-            best_idx[k] = c0 + i;
+          if (m[k] > 0.0f) {
+            // losses.py:12-21 (iw, ih > 0 here, so the clamps at 0 are no-ops)
+            const float inter = iw[k] * ih[k];
+            float ua = (area_a[k] + ab) - inter;
+            ua = fmaxf(ua, 1e-8f);
+            // The correctly rounded quotient can exceed `best` only if inter > best*ua*(1 - 2^-23);
+            // test that first (with margin) and divide only for the few boxes that can win.
+            if (inter >= (best[k] * ua) * 0.999999f) {
+              const float v = inter / ua;
+              if (v > best[k]) {
+                best[k] = v;
+                best_idx[k] = c0 + i;
+              }
+            }
           }
         }
       }
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     int t = 0;
 #pragma unroll
     for (int w = 0; w < kThreads / 64; ++w) t += s_pos[w];
-    if (t) atomicAdd(&num_pos[j], t);   // integer add: order-independent
+    if (t) atomicAdd(&num_pos[(size_t)j * pos_stride], t);   // integer add: order-independent
   }
 }
 
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ num_pos, float* __restrict__ partials,
     int N, int C, int M, int total_rows, int num_tiles, unsigned magic_c, FocalConst fc,
-    float gcls, float greg, float divisor) {
+    float gcls, float greg, float divisor, int pos_stride) {
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
   const int tid = threadIdx.x;
@@ -342,8 +351,8 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const int j0 = row0 / N;
     const int split = (j0 + 1) * N - row0;            // first tile-local row of image j0+1
     const bool two = split < rows;
-    const int np0 = num_pos[j0];
-    const int np1 = two ? num_pos[j0 + 1] : 0;
+    const int np0 = num_pos[(size_t)j0 * pos_stride];
+    const int np1 = two ? num_pos[(size_t)(j0 + 1) * pos_stride] : 0;
     const float norm0 = (float)max(np0, 1), norm1 = (float)max(np1, 1);
     const float sc0 = gcls / (norm0 * divisor), sc1 = gcls / (norm1 * divisor);
 
@@ -499,12 +508,12 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ num_pos, float* __restrict__ partials,
-    int N, int C, int M, FocalConst fc, float gcls, float greg, float divisor) {
+    int N, int C, int M, FocalConst fc, float gcls, float greg, float divisor, int pos_stride) {
   __shared__ float s_red[4];
   const int j = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int np = num_pos[j];
+  const int np = num_pos[(size_t)j * pos_stride];
   const float sc = gcls / ((float)max(np, 1) * divisor);
   const float rsc = greg / ((4.0f * (float)np) * divisor);
   float cl = 0.f, rl = 0.f;
@@ -553,13 +562,15 @@ constexpr int kFinalThreads = 1024;
 __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     const float* __restrict__ partials, const int* __restrict__ num_pos,
     const int* __restrict__ gt_count, float* __restrict__ per_image, int* __restrict__ num_pos_out,
-    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor) {
+    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor,
+    int pos_stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int j = wave; j < B; j += kFinalThreads / 64) {
     double c = 0.0, r = 0.0;
     if (tile_mode) {
       const long long first = (long long)j * N, last = first + N - 1;
       const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
+#pragma unroll 8
       for (int t = t_lo + lane; t <= t_hi; t += 64) {
         const int slot = j - (int)(((long long)t * kTileRows) / N);   // 0 or 1
         const float4 q = reinterpret_cast<const float4*>(partials)[t];
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     c = wave_sum(c);
     r = wave_sum(r);
     if (lane == 0) {
-      const int np = num_pos[j];
+      const int np = num_pos[(size_t)j * pos_stride];
       const bool empty = gt_count[j] == 0;
       per_image[j] = empty ? 0.f : (float)c / (float)max(np, 1);
       per_image[B + j] = (empty || np == 0) ? 0.f : (float)r / (4.0f * (float)np);
@@ -648,7 +659,7 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   LossWorkspace w;
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.num_pos = cv.take<int>(batch);
+  w.num_pos = cv.take<int>((size_t)batch * kPosStride);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
   w.per_image = cv.take<float>((size_t)2 * batch);
@@ -670,15 +681,15 @@ static int check_assign_shapes(int batch, long long n, int m, int c) {
 static int launch_assign(const float* anchors, const float* annotations, int batch, long long n,
                          int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                          unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
-                         hipStream_t s) {
+                         int pos_stride, hipStream_t s) {
   hipLaunchKernelGGL(gt_prepare_kernel, dim3(batch), dim3(64), 0, s, annotations, w.gt, w.gt_count,
-                     w.num_pos, status, m, c);
+                     w.num_pos, status, m, c, pos_stride);
   RH_CHECK_LAUNCH("gt_prepare_kernel");
   const int per_block = kThreads * kAssignPer;
   dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)batch);
   hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
                      reinterpret_cast<const float4*>(anchors), w.gt, w.gt_count, code, state, argmax,
-                     label, iou_max, w.num_pos, (int)n, m, neg_t, pos_t);
+                     label, iou_max, w.num_pos, (int)n, m, neg_t, pos_t, pos_stride);
   RH_CHECK_LAUNCH("assign_kernel");
   return RH_OK;
 }
@@ -731,7 +742,7 @@ int rh_assign(const float* anchors, const float* annotations, int32_t batch, int
   cv.take<int>(batch);
   w.num_pos = num_pos;
   return launch_assign(anchors, annotations, batch, n, m, num_classes, neg_thresh, pos_thresh, w,
-                       nullptr, state, argmax, label, iou_max, status, (hipStream_t)stream);
+                       nullptr, state, argmax, label, iou_max, status, 1, (hipStream_t)stream);
 }
 
 size_t rh_focal_loss_workspace_bytes(int32_t batch, int64_t n, int32_t num_classes, int32_t m) {
@@ -769,7 +780,7 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   if (stages & RH_STAGE_ASSIGN) {
     if (int e = launch_assign(anchors, annotations, batch, n, m, num_classes, params->neg_thresh,
                               params->pos_thresh, w, w.code, nullptr, nullptr, nullptr, nullptr,
-                              status, s))
+                              status, kPosStride, s))
       return e;
   }
   if (stages & RH_STAGE_STREAM) {
@@ -785,7 +796,7 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
       const int var = ev ? atoi(ev) : 3;
       void (*kern)(const float*, float*, const float*, float*, const float4*, const GtRec*,
                    const int*, const int*, float*, int, int, int, int, int, unsigned, FocalConst,
-                   float, float, float);
+                   float, float, float, int);
       if (u5) {
         kern = var == 0 ? focal_stream_kernel<5, false, false>
              : var == 1 ? focal_stream_kernel<5, true, false>
@@ -802,13 +813,13 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.num_pos,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
                          div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
-                         divisor);
+                         divisor, kPosStride);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
       hipLaunchKernelGGL(focal_rows_kernel, dim3(kGenericBlocks, batch), dim3(kThreads), 0, s,
                          classifications, d_classifications, regressions, d_regressions, anchors,
                          w.gt, w.code, w.num_pos, w.partials, (int)n, num_classes, m, fc,
-                         params->grad_cls, params->grad_reg, divisor);
+                         params->grad_cls, params->grad_reg, divisor, kPosStride);
       RH_CHECK_LAUNCH("focal_rows_kernel");
     }
   }
@@ -816,7 +827,7 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
     float* pi = per_image ? per_image : w.per_image;
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.num_pos,
                        w.gt_count, pi, num_pos, losses, batch, (int)n, tile ? 1 : 0, kGenericBlocks,
-                       divisor);
+                       divisor, kPosStride);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage: tools/rocprof_stages.sh <outdir-under-gpurun_out> <bench_stages args...>
+# rocprofv3 kernel-trace + stats of tools/bench_stages.py; run on the GPU box.
+set -e
+out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/bench_stages.py "$@" > $out/run.log 2>&1
+python3 - "$out" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/*/*kernel_stats.csv')[0]
+for r in list(csv.DictReader(open(f)))[:14]:
+    print(f"{r['Name'][:64]:64s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} min={float(r['MinNs'])/1e3:9.2f} max={float(r['MaxNs'])/1e3:9.2f}")
+PY
