@@ -8,7 +8,6 @@
 // Everything is HBM-bound float32 streaming; there is no contraction, so no MFMA.
 // The file is compiled with -ffp-contract=off: IoU values feed thresholds and an
 // arg-max whose integer results must equal the reference's bit for bit.
-#include <stdlib.h>
 #include "rh_common.h"
 
 namespace rh {
@@ -332,7 +331,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // Requirements checked on the host: 4 <= C < 8192, N >= 64, all pointers 16-byte
 // aligned, B*N < 2^31.
 // ---------------------------------------------------------------------------
-template <int U, bool NTL, bool NTS>
+template <int U>
 __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
@@ -404,7 +403,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) val[u] = NTL ? __builtin_nontemporal_load(&p4[v]) : p4[v];
+          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
             cl0 += focal_zero(val[u].w, fc, k0l, k0g, g3);
             v4f o;
             o.x = g0; o.y = g1; o.z = g2; o.w = g3;
-            if (NTS) __builtin_nontemporal_store(o, &d4[v]); else d4[v] = o;
+            __builtin_nontemporal_store(o, &d4[v]);
           }
         }
       }
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) val[u] = NTL ? __builtin_nontemporal_load(&p4[v]) : p4[v];
+          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
         }
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
             }
             v4f o;
             o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
-            if (NTS) __builtin_nontemporal_store(o, &d4[v]); else d4[v] = o;
+            __builtin_nontemporal_store(o, &d4[v]);
           }
         }
       }
@@ -788,27 +787,11 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
       // float4 slots per thread and tile: pick the unroll that wastes the fewest
       const int per_thread = (kTileRows * num_classes / 4 + kThreads - 1) / kThreads;
       const bool u5 = (per_thread + 4) / 5 * 5 < (per_thread + 3) / 4 * 4;
-      // tuning knobs (experiments only)
-      const char* eg = getenv("RH_STREAM_GRID");
-      const char* ev = getenv("RH_STREAM_VARIANT");
-      int grid2 = eg ? atoi(eg) : num_tiles;
-      if (grid2 <= 0 || grid2 > num_tiles) grid2 = num_tiles;
-      const int var = ev ? atoi(ev) : 3;
-      void (*kern)(const float*, float*, const float*, float*, const float4*, const GtRec*,
-                   const int*, const int*, float*, int, int, int, int, int, unsigned, FocalConst,
-                   float, float, float, int);
-      if (u5) {
-        kern = var == 0 ? focal_stream_kernel<5, false, false>
-             : var == 1 ? focal_stream_kernel<5, true, false>
-             : var == 2 ? focal_stream_kernel<5, false, true>
-                        : focal_stream_kernel<5, true, true>;
-      } else {
-        kern = var == 0 ? focal_stream_kernel<4, false, false>
-             : var == 1 ? focal_stream_kernel<4, true, false>
-             : var == 2 ? focal_stream_kernel<4, false, true>
-                        : focal_stream_kernel<4, true, true>;
-      }
-      hipLaunchKernelGGL(kern, dim3(grid2), dim3(kThreads), 0, s, classifications,
+      // One tile per workgroup: the hardware dispatcher balances the 17k+ tiles better than a
+      // grid-stride loop did (measured 125 us against 142 us at B=16, N=69354, C=80), and
+      // non-temporal loads and stores (the data is touched once) were worth another 8 %.
+      auto kern = u5 ? focal_stream_kernel<5> : focal_stream_kernel<4>;
+      hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications,
                          d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.num_pos,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
