@@ -73,14 +73,14 @@ def event_times(fn, iters):
     return float(np.mean(ms)), float(np.min(ms))
 
 
-def cpu_baseline(cls, reg, anc, ann, sample_images, threads):
+def cpu_baseline(cls, reg, anc, ann, sample_images, threads, reps):
     from oracle import torch_cpu_path as T
     torch.set_num_threads(threads)
     c = torch.from_numpy(cls[:sample_images]).clone().requires_grad_(True)
     r = torch.from_numpy(reg[:sample_images]).clone().requires_grad_(True)
     a, an = torch.from_numpy(anc), torch.from_numpy(ann[:sample_images])
     best = float("inf")
-    for _ in range(3):
+    for _ in range(reps):
         c.grad = r.grad = None
         t0 = time.perf_counter()
         out = T.dense_head_loss(c, r, a, an)
@@ -245,22 +245,41 @@ def main():
     algo_bytes = BATCH * n * (8 * CLASSES + 48)
     achieved = algo_bytes / (k_mean * 1e-3) / 1e9
     traffic = None
+    # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this same
+    # configuration; they cannot be read inside this process, so the committed summary is used.
     tfile = os.path.join(ROOT, "profiles", "traffic_focal_stream.json")
     if os.path.exists(tfile):
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
 
-    # ---- decode + NMS (secondary metric) -------------------------------------------------------
+    # ---- decode + NMS (second half of the metric) ------------------------------------------
     icls_np, ireg_np = synth_infer(np.random.default_rng(3000), BATCH, n, CLASSES)
     icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
-    post = lambda: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, cand_cap=4096)
+    post = lambda out=None: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, cand_cap=4096, out=out)
     res = post()
     counts = res["counts"].cpu().numpy()
     for _ in range(5):
-        post()
-    p_mean, p_min = event_times(post, 50)
+        post(res)
+    p_mean, p_min = event_times(lambda: post(res), 50)
     d_mean, _ = event_times(lambda: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, cand_cap=4096,
                                                       stages=_lib.POST_DECODE, out=res), 50)
     decode_bytes = BATCH * n * (4 * CLASSES + 32)
+    # Batches in flight on three streams (each with its own workspace and outputs): the per-image
+    # sort and sweep occupy one CU per image, so they overlap the next batch's score scan.
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    outs = []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            outs.append(post())
+    torch.cuda.synchronize()
+    rounds = 40
+    t1 = time.perf_counter()
+    for _ in range(rounds):
+        for st, o in zip(streams, outs):
+            with torch.cuda.stream(st):
+                post(o)
+    torch.cuda.synchronize()
+    piped_ms = (time.perf_counter() - t1) / (rounds * len(streams)) * 1e3
 
     line = {
         "metric": "focal_loss_fwd_bwd_anchors_per_sec",
@@ -285,19 +304,23 @@ def main():
                      "traffic": traffic, "algorithmic_bytes": algo_bytes,
                      "kernel_ms_mean": k_mean, "kernel_ms_min": k_min},
         "kernels_ms": {"assign_stage": a_mean, "stream_stage": k_mean, "fused_call": f_mean},
-        "decode_nms": {"images_per_s": BATCH / (p_mean * 1e-3), "ms_per_batch": p_mean,
-                       "ms_min": p_min, "decode_stage_ms": d_mean,
-                       "decode_stage_frac_of_hbm_peak": decode_bytes / (d_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "decode_nms": {"images_per_s": BATCH / (piped_ms * 1e-3), "ms_per_batch": piped_ms,
+                       "launch": "3 batches in flight on 3 HIP streams",
+                       "frac_of_hbm_peak": decode_bytes / (piped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "single_stream_images_per_s": BATCH / (p_mean * 1e-3),
+                       "single_stream_ms_per_batch": p_mean, "single_stream_ms_min": p_min,
+                       "scan_stage_ms": d_mean,
+                       "scan_stage_frac_of_hbm_peak": decode_bytes / (d_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "candidates_per_image": float(counts[1].mean()),
                        "kept_per_image": float(counts[0].mean()), "mode": "agnostic, thr 0.05, IoU 0.5"},
     }
     if not args.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)
-        sample = 4
-        v, secs = cpu_baseline(cls_np, reg_np, anc_np, ann_np, sample, threads)
+        sample, reps = BATCH, 20
+        v, secs = cpu_baseline(cls_np, reg_np, anc_np, ann_np, sample, threads, reps)
         line["cpu_baseline"] = {"value": v, "unit": "anchors/s", "cores": threads, "kind": "port",
-                                "sample": f"{sample} images of the same batch (N={n}, C={CLASSES}), "
-                                          f"forward+backward, best of 3, {secs:.2f} s each"}
+                                "sample": f"the whole batch ({sample} images, N={n}, C={CLASSES}), "
+                                          f"forward+backward, best of {reps} runs of {secs:.2f} s"}
     print(json.dumps(line))
     if world > 1:
         dist.barrier()
