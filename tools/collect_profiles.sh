@@ -8,7 +8,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 $GRAFT_REPO_ROOT/bench.py > $out/bench_stdout.log 2>&1
-tail -1 $out/bench_stdout.log > $out/bench_line_under_rocprof.json
+grep "^{\"metric\"" $out/bench_stdout.log > $out/bench_line_under_rocprof.json || true
 cp $(ls $out/bench/*/*kernel_stats.csv | head -1) $out/${tag}_bench_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/train -- python3 $GRAFT_REPO_ROOT/tools/bench_stages.py --cfg 2 > $out/train_stdout.log 2>&1
 cp $(ls $out/train/*/*kernel_stats.csv | head -1) $out/${tag}_loss_stages_kernel_stats.csv
