@@ -110,7 +110,7 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 // Max / first arg-max (losses.py:61), thresholds (:70-72), label lookup (:76-79),
 // positive count (:74).
 // ---------------------------------------------------------------------------
-constexpr int kAssignPer = 4;
+constexpr int kAssignPer = 2;
 
 __global__ __launch_bounds__(kThreads) void assign_kernel(
     const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
