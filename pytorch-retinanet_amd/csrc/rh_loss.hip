@@ -34,58 +34,6 @@ constexpr int kTileRows = 64;      // anchors per stream tile
 constexpr int kThreads = 256;
 constexpr int kGtChunk = 256;      // GT boxes staged in LDS at a time
 constexpr int kGenericBlocks = 64; // blocks per image of the generic row kernel
-constexpr int kPosStride = 32;     // ints between per-image positive counters: one 128-byte line
-                                   // each, so the blocks' atomic adds do not queue on one line
-
-// ---------------------------------------------------------------------------
-// GT compaction: keeps rows with label != -1 in order (losses.py:48-49), stores
-// their areas (losses.py:7) and truncated labels (.long(), losses.py:79), and
-// zeroes the per-image positive counters.  One wave per image.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void gt_prepare_kernel(const float* __restrict__ ann,
-                                                        GtRec* __restrict__ gt,
-                                                        int* __restrict__ gt_count,
-                                                        int* __restrict__ num_pos,
-                                                        int* __restrict__ status, int M, int C,
-                                                        int pos_stride) {
-  const int j = blockIdx.x;
-  const int lane = threadIdx.x;
-  const float* a = ann + (size_t)j * M * 5;
-  GtRec* out = gt + (size_t)j * M;
-  int base = 0;
-  int bad = 0;
-  for (int m0 = 0; m0 < M; m0 += 64) {
-    const int m = m0 + lane;
-    float lab = -1.0f;
-    if (m < M) lab = a[m * 5 + 4];
-    const bool valid = (m < M) && (lab != -1.0f);
-    const unsigned long long mask = __ballot(valid);
-    if (valid) {
-      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-      GtRec r;
-      r.x1 = a[m * 5 + 0];
-      r.y1 = a[m * 5 + 1];
-      r.x2 = a[m * 5 + 2];
-      r.y2 = a[m * 5 + 3];
-      r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
-      int l = (int)lab;
-      if (!(lab > -1.0f && lab < (float)C)) {   // also catches NaN
-        l = -1;
-        bad = 1;
-      }
-      r.label = l;
-      r.pad0 = r.pad1 = 0;
-      out[slot] = r;
-    }
-    base += __popcll(mask);
-  }
-  const unsigned long long any_bad = __ballot(bad != 0);
-  if (lane == 0) {
-    gt_count[j] = base;
-    num_pos[(size_t)j * pos_stride] = 0;
-    if (status) status[j] = any_bad ? RH_STATUS_LABEL_RANGE : 0;
-  }
-}
 
 // ---------------------------------------------------------------------------
 // IoU of one anchor with one GT, float32, operation order of losses.py:9-21.
@@ -104,31 +52,40 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 }
 
 // ---------------------------------------------------------------------------
-// Assignment: kAssignPer anchors per thread (strided by the block size, so loads
-// and stores stay coalesced); the image's GT boxes are staged through LDS in
-// chunks and read as wave-uniform broadcasts, once for all of a thread's anchors.
-// Max / first arg-max (losses.py:61), thresholds (:70-72), label lookup (:76-79),
-// positive count (:74).
+// Assignment, one launch: GT filter + IoU + max / first arg-max + thresholds + labels.
+//
+// Every block compacts its image's annotation rows itself (rows with label != -1, in order,
+// losses.py:48-49; areas losses.py:7; labels truncated like .long(), losses.py:79), 256 rows
+// at a time into LDS, and scans them for its anchors: kAssignPer anchors per thread (strided
+// by the block size, so loads and stores stay coalesced), GT boxes read as wave-uniform
+// broadcasts.  Block 0 of each image also publishes the compacted records, the valid count
+// and the status word for the kernels that follow.  Positives are counted per block into
+// blk_pos[image][block]: no atomics and nothing to zero beforehand.
+// Max / first arg-max (losses.py:61), thresholds (:70-72), label lookup (:76-79), count (:74).
 // ---------------------------------------------------------------------------
 constexpr int kAssignPer = 2;
+constexpr int kAssignBlock = kThreads * kAssignPer;   // anchors per block
 
 __global__ __launch_bounds__(kThreads) void assign_kernel(
-    const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
-    const int* __restrict__ gt_count, int* __restrict__ code, unsigned char* __restrict__ state,
-    int* __restrict__ argmax, int* __restrict__ label, float* __restrict__ iou_max,
-    int* __restrict__ num_pos, int N, int M, float neg_thresh, float pos_thresh, int pos_stride) {
+    const float4* __restrict__ anchors, const float* __restrict__ ann, GtRec* __restrict__ gt,
+    int* __restrict__ gt_count, int* __restrict__ status, int* __restrict__ code,
+    unsigned char* __restrict__ state, int* __restrict__ argmax, int* __restrict__ label,
+    float* __restrict__ iou_max, int* __restrict__ blk_pos, int N, int M, int C,
+    float neg_thresh, float pos_thresh) {
   __shared__ float4 s_box[kGtChunk];
   __shared__ float s_area[kGtChunk];
-  __shared__ int s_pos[kThreads / 64];
+  __shared__ int s_lab[kGtChunk];
+  __shared__ int s_cnt[kThreads / 64];
 
   const int j = blockIdx.y;
-  const int base = blockIdx.x * (kThreads * kAssignPer) + threadIdx.x;
-  const int cnt = gt_count[j];
-  const GtRec* g = gt + (size_t)j * M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * kAssignBlock + threadIdx.x;
+  const float* aj = ann + (size_t)j * M * 5;
+  const bool publisher = blockIdx.x == 0;
 
   float4 a[kAssignPer];
   float area_a[kAssignPer], best[kAssignPer];
-  int best_idx[kAssignPer];
+  int best_idx[kAssignPer], best_lab[kAssignPer];
 #pragma unroll
   for (int k = 0; k < kAssignPer; ++k) {
     const int n = base + k * kThreads;
@@ -136,35 +93,70 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     area_a[k] = (a[k].z - a[k].x) * (a[k].w - a[k].y);
     best[k] = 0.0f;   // every IoU is >= 0, so "first maximum" starts at (0, index 0)
     best_idx[k] = 0;
+    best_lab[k] = -2; // "label of valid GT 0", resolved below if nothing beats IoU 0
   }
-  for (int c0 = 0; c0 < cnt; c0 += kGtChunk) {
-    const int len = min(kGtChunk, cnt - c0);
+
+  int cnt = 0;        // valid GT rows seen so far
+  int bad = 0;
+  int lab0 = -1;      // label of the image's first valid GT (arg-max of an all-zero IoU row)
+  for (int m0 = 0; m0 < M; m0 += kGtChunk) {
+    // ---- stage: one annotation row per thread, keep the valid ones, in order
+    const int m = m0 + (int)threadIdx.x;
+    float lab = -1.0f;
+    if (m < M) lab = aj[m * 5 + 4];
+    const bool valid = m < M && lab != -1.0f;
+    const unsigned long long vm = __ballot(valid);
+    __syncthreads();                       // previous chunk's readers are done
+    if (lane == 0) s_cnt[wave] = __popcll(vm);
     __syncthreads();
-    for (int i = threadIdx.x; i < len; i += kThreads) {
-      const GtRec r = g[c0 + i];
-      s_box[i] = make_float4(r.x1, r.y1, r.x2, r.y2);
-      s_area[i] = r.area;
+    int slot = __popcll(vm & ((1ull << lane) - 1ull)), len = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+      slot += w < wave ? s_cnt[w] : 0;
+      len += s_cnt[w];
+    }
+    if (valid) {
+      GtRec r;
+      r.x1 = aj[m * 5 + 0];
+      r.y1 = aj[m * 5 + 1];
+      r.x2 = aj[m * 5 + 2];
+      r.y2 = aj[m * 5 + 3];
+      r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
+      int l = (int)lab;
+      if (!(lab > -1.0f && lab < (float)C)) {   // also catches NaN
+        l = -1;
+        bad = 1;
+      }
+      r.label = l;
+      r.pad0 = r.pad1 = 0;
+      s_box[slot] = make_float4(r.x1, r.y1, r.x2, r.y2);
+      s_area[slot] = r.area;
+      s_lab[slot] = l;
+      if (publisher) gt[(size_t)j * M + cnt + slot] = r;
     }
     __syncthreads();
+    if (cnt == 0 && len > 0) lab0 = s_lab[0];
+    // ---- scan the chunk's valid boxes
 #pragma unroll 2
     for (int i = 0; i < len; ++i) {
       const float4 b = s_box[i];
       // overlap test for the thread's anchors first; one (rare) branch per GT box
-      float iw[kAssignPer], ih[kAssignPer], m[kAssignPer];
+      float iw[kAssignPer], ih[kAssignPer], mm[kAssignPer];
 #pragma unroll
       for (int k = 0; k < kAssignPer; ++k) {
         iw[k] = fminf(a[k].z, b.z) - fmaxf(a[k].x, b.x);
         ih[k] = fminf(a[k].w, b.w) - fmaxf(a[k].y, b.y);
-        m[k] = fminf(iw[k], ih[k]);
+        mm[k] = fminf(iw[k], ih[k]);
       }
-      float any = m[0];
+      float any = mm[0];
 #pragma unroll
-      for (int k = 1; k < kAssignPer; ++k) any = fmaxf(any, m[k]);
+      for (int k = 1; k < kAssignPer; ++k) any = fmaxf(any, mm[k]);
       if (any > 0.0f) {
         const float ab = s_area[i];
+        const int lb = s_lab[i];
 #pragma unroll
         for (int k = 0; k < kAssignPer; ++k) {
-          if (m[k] > 0.0f) {
+          if (mm[k] > 0.0f) {
             // losses.py:12-21 (iw, ih > 0 here, so the clamps at 0 are no-ops)
             const float inter = iw[k] * ih[k];
             float ua = (area_a[k] + ab) - inter;
@@ -175,13 +167,15 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
               const float v = inter / ua;
               if (v > best[k]) {
                 best[k] = v;
-                best_idx[k] = c0 + i;
+                best_idx[k] = cnt + i;
+                best_lab[k] = lb;
               }
             }
           }
         }
       }
     }
+    cnt += len;
   }
 
   int npos = 0;
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
       cd = kCodeIgn;
     } else if (best[k] >= pos_thresh) {
       st = RH_POSITIVE;
-      lb = g[best_idx[k]].label;
+      lb = best_lab[k] == -2 ? lab0 : best_lab[k];
       cd = (best_idx[k] << 16) | (lb < 0 ? kNoLabel : lb);
     } else if (best[k] < neg_thresh) {
       st = RH_NEGATIVE;
@@ -214,14 +208,42 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     }
   }
   npos = wave_sum(npos);
-  if ((threadIdx.x & 63) == 0) s_pos[threadIdx.x >> 6] = npos;
+  const int any_bad = __syncthreads_or(bad);   // also orders the s_cnt reuse below
+  if (lane == 0) s_cnt[wave] = npos;
   __syncthreads();
   if (threadIdx.x == 0) {
     int t = 0;
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) t += s_pos[w];
-    if (t) atomicAdd(&num_pos[(size_t)j * pos_stride], t);   // integer add: order-independent
+    for (int w = 0; w < kThreads / 64; ++w) t += s_cnt[w];
+    blk_pos[(size_t)j * gridDim.x + blockIdx.x] = t;
+    if (publisher) {
+      gt_count[j] = cnt;
+      if (status) status[j] = any_bad ? RH_STATUS_LABEL_RANGE : 0;
+    }
   }
+}
+
+// Sum of an image's per-block positive counts; all threads of the block call it and get the
+// same value.  s_tmp: kThreads / 64 ints of LDS.
+__device__ __forceinline__ int sum_blk_pos(const int* __restrict__ blk_pos, const int nblk,
+                                           const int j, int* s_tmp) {
+  int v = 0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) v += blk_pos[(size_t)j * nblk + i];
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_tmp[w];
+  return t;
+}
+
+__global__ __launch_bounds__(kThreads) void sum_blk_pos_kernel(const int* __restrict__ blk_pos,
+                                                               int nblk,
+                                                               int* __restrict__ num_pos) {
+  __shared__ int s_tmp[kThreads / 64];
+  const int t = sum_blk_pos(blk_pos, nblk, blockIdx.x, s_tmp);
+  if (threadIdx.x == 0) num_pos[blockIdx.x] = t;
 }
 
 // Full IoU matrix (losses.py:6-23), one thread per output element.
@@ -335,11 +357,12 @@ template <int U>
 __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
-    const int* __restrict__ code, const int* __restrict__ num_pos, float* __restrict__ partials,
-    int N, int C, int M, int total_rows, int num_tiles, unsigned magic_c, FocalConst fc,
-    float gcls, float greg, float divisor, int pos_stride) {
+    const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
+    float* __restrict__ partials, int N, int C, int M, int total_rows, int num_tiles,
+    unsigned magic_c, FocalConst fc, float gcls, float greg, float divisor) {
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
+  __shared__ int s_np[kThreads / 64][2];
   const int tid = threadIdx.x;
   const float k0l = -(1.0f - fc.alpha) * kLn2;
   constexpr int UG = 2;   // unroll of the general (row-tracking) path: keeps registers low
@@ -350,17 +373,29 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const int j0 = row0 / N;
     const int split = (j0 + 1) * N - row0;            // first tile-local row of image j0+1
     const bool two = split < rows;
-    const int np0 = num_pos[(size_t)j0 * pos_stride];
-    const int np1 = two ? num_pos[(size_t)(j0 + 1) * pos_stride] : 0;
-    const float norm0 = (float)max(np0, 1), norm1 = (float)max(np1, 1);
-    const float sc0 = gcls / (norm0 * divisor), sc1 = gcls / (norm1 * divisor);
+    // positives of the tile's image(s): sum of the assignment kernel's per-block counts
+    int v0 = 0, v1 = 0;
+    for (int i = tid; i < nblk; i += kThreads) {
+      v0 += blk_pos[(size_t)j0 * nblk + i];
+      if (two) v1 += blk_pos[(size_t)(j0 + 1) * nblk + i];
+    }
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
 
-    __syncthreads();   // previous tile's readers of s_code / s_red are done
+    __syncthreads();   // previous tile's readers of s_code / s_red / s_np are done
+    if ((tid & 63) == 0) {
+      s_np[tid >> 6][0] = v0;
+      s_np[tid >> 6][1] = v1;
+    }
     int my_code = kCodeNeg;
     if (tid < rows) my_code = code[row0 + tid];
     if (tid < kTileRows) s_code[tid] = tid < rows ? my_code : kCodeIgn;
-    // any positive or ignored row in this tile?  (also the barrier that publishes s_code)
+    // any positive or ignored row in this tile?  (also the barrier that publishes s_code, s_np)
     const int special = __syncthreads_or(my_code != kCodeNeg);
+    const int np0 = (s_np[0][0] + s_np[1][0]) + (s_np[2][0] + s_np[3][0]);
+    const int np1 = (s_np[0][1] + s_np[1][1]) + (s_np[2][1] + s_np[3][1]);
+    const float norm0 = (float)max(np0, 1), norm1 = (float)max(np1, 1);
+    const float sc0 = gcls / (norm0 * divisor), sc1 = gcls / (norm1 * divisor);
 
     float cl0 = 0.f, cl1 = 0.f, rl0 = 0.f, rl1 = 0.f;
 
@@ -506,13 +541,15 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
 __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float* __restrict__ anchors, const GtRec* __restrict__ gt,
-    const int* __restrict__ code, const int* __restrict__ num_pos, float* __restrict__ partials,
-    int N, int C, int M, FocalConst fc, float gcls, float greg, float divisor, int pos_stride) {
+    const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
+    float* __restrict__ partials, int N, int C, int M, FocalConst fc, float gcls, float greg,
+    float divisor) {
   __shared__ float s_red[4];
+  __shared__ int s_tmp[kThreads / 64];
   const int j = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int np = num_pos[(size_t)j * pos_stride];
+  const int np = sum_blk_pos(blk_pos, nblk, j, s_tmp);
   const float sc = gcls / ((float)max(np, 1) * divisor);
   const float rsc = greg / ((4.0f * (float)np) * divisor);
   float cl = 0.f, rl = 0.f;
@@ -559,53 +596,69 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
 constexpr int kFinalThreads = 1024;
 
 __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
-    const float* __restrict__ partials, const int* __restrict__ num_pos,
+    const float* __restrict__ partials, const int* __restrict__ blk_pos, int nblk,
     const int* __restrict__ gt_count, float* __restrict__ per_image, int* __restrict__ num_pos_out,
-    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor,
-    int pos_stride) {
+    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor) {
+  __shared__ float s_img[2][kFinalThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < B; j += kFinalThreads / 64) {
-    double c = 0.0, r = 0.0;
-    if (tile_mode) {
-      const long long first = (long long)j * N, last = first + N - 1;
-      const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
+  double bc = 0.0, br = 0.0;     // wave 0 only: batch sums, images visited in ascending order
+  for (int j0 = 0; j0 < B; j0 += kFinalThreads / 64) {
+    const int j = j0 + wave;
+    float cl = 0.f, rl = 0.f;
+    if (j < B) {
+      double c = 0.0, r = 0.0;
+      if (tile_mode) {
+        const long long first = (long long)j * N, last = first + N - 1;
+        const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
+        // only the image's first tile can also hold rows of the previous image; there this
+        // image is the tile's second one
+        const bool shared_first = (first % kTileRows) != 0;
 #pragma unroll 8
-      for (int t = t_lo + lane; t <= t_hi; t += 64) {
-        const int slot = j - (int)(((long long)t * kTileRows) / N);   // 0 or 1
-        const float4 q = reinterpret_cast<const float4*>(partials)[t];
-        c += slot ? q.y : q.x;
-        r += slot ? q.w : q.z;
+        for (int t = t_lo + lane; t <= t_hi; t += 64) {
+          const float4 q = reinterpret_cast<const float4*>(partials)[t];
+          const bool second = shared_first && t == t_lo;
+          c += second ? q.y : q.x;
+          r += second ? q.w : q.z;
+        }
+      } else {
+        for (int t = lane; t < generic_blocks; t += 64) {
+          c += partials[((size_t)j * generic_blocks + t) * 2];
+          r += partials[((size_t)j * generic_blocks + t) * 2 + 1];
+        }
       }
-    } else {
-      for (int t = lane; t < generic_blocks; t += 64) {
-        c += partials[((size_t)j * generic_blocks + t) * 2];
-        r += partials[((size_t)j * generic_blocks + t) * 2 + 1];
+      int np = 0;
+      for (int i = lane; i < nblk; i += 64) np += blk_pos[(size_t)j * nblk + i];
+      c = wave_sum(c);
+      r = wave_sum(r);
+      np = wave_sum(np);
+      const bool empty = gt_count[j] == 0;
+      cl = empty ? 0.f : (float)c / (float)max(np, 1);
+      rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * (float)np);
+      if (lane == 0) {
+        if (per_image) {
+          per_image[j] = cl;
+          per_image[B + j] = rl;
+        }
+        if (num_pos_out) num_pos_out[j] = np;
       }
     }
-    c = wave_sum(c);
-    r = wave_sum(r);
+    __syncthreads();
     if (lane == 0) {
-      const int np = num_pos[(size_t)j * pos_stride];
-      const bool empty = gt_count[j] == 0;
-      per_image[j] = empty ? 0.f : (float)c / (float)max(np, 1);
-      per_image[B + j] = (empty || np == 0) ? 0.f : (float)r / (4.0f * (float)np);
-      if (num_pos_out) num_pos_out[j] = np;
+      s_img[0][wave] = cl;
+      s_img[1][wave] = rl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 0; w < kFinalThreads / 64; ++w) {
+        bc += s_img[0][w];
+        br += s_img[1][w];
+      }
     }
   }
-  __threadfence_block();
-  __syncthreads();
-  if (wave == 0) {
-    double c = 0.0, r = 0.0;
-    for (int j = lane; j < B; j += 64) {
-      c += per_image[j];
-      r += per_image[B + j];
-    }
-    c = wave_sum(c);
-    r = wave_sum(r);
-    if (lane == 0) {
-      losses[0] = (float)(c / (double)divisor);
-      losses[1] = (float)(r / (double)divisor);
-    }
+  if (threadIdx.x == 0) {
+    losses[0] = (float)(bc / (double)divisor);
+    losses[1] = (float)(br / (double)divisor);
   }
 }
 
@@ -638,10 +691,10 @@ __global__ __launch_bounds__(kThreads) void apply_upstream_kernel(
 struct LossWorkspace {
   GtRec* gt;
   int* gt_count;
-  int* num_pos;
+  int* blk_pos;      // [B][assign blocks per image]
+  int nblk;
   int* code;
   float* partials;
-  float* per_image;
   size_t bytes;
 };
 
@@ -658,10 +711,10 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   LossWorkspace w;
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.num_pos = cv.take<int>((size_t)batch * kPosStride);
+  w.nblk = (int)((n + kAssignBlock - 1) / kAssignBlock);
+  w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
-  w.per_image = cv.take<float>((size_t)2 * batch);
   w.bytes = cv.off;
   return w;
 }
@@ -680,15 +733,11 @@ static int check_assign_shapes(int batch, long long n, int m, int c) {
 static int launch_assign(const float* anchors, const float* annotations, int batch, long long n,
                          int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                          unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
-                         int pos_stride, hipStream_t s) {
-  hipLaunchKernelGGL(gt_prepare_kernel, dim3(batch), dim3(64), 0, s, annotations, w.gt, w.gt_count,
-                     w.num_pos, status, m, c, pos_stride);
-  RH_CHECK_LAUNCH("gt_prepare_kernel");
-  const int per_block = kThreads * kAssignPer;
-  dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)batch);
+                         hipStream_t s) {
+  dim3 grid((unsigned)w.nblk, (unsigned)batch);
   hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
-                     reinterpret_cast<const float4*>(anchors), w.gt, w.gt_count, code, state, argmax,
-                     label, iou_max, w.num_pos, (int)n, m, neg_t, pos_t, pos_stride);
+                     reinterpret_cast<const float4*>(anchors), annotations, w.gt, w.gt_count, status,
+                     code, state, argmax, label, iou_max, w.blk_pos, (int)n, m, c, neg_t, pos_t);
   RH_CHECK_LAUNCH("assign_kernel");
   return RH_OK;
 }
@@ -715,13 +764,20 @@ int rh_calc_iou_f32(const float* a, int64_t n, const float* b, int64_t m, float*
   return RH_OK;
 }
 
+static LossWorkspace carve_assign(void* ws, int batch, long long n, int m) {
+  Carver cv(ws);
+  LossWorkspace w{};
+  w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
+  w.gt_count = cv.take<int>(batch);
+  w.nblk = (int)((n + kAssignBlock - 1) / kAssignBlock);
+  w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
+  w.bytes = cv.off;
+  return w;
+}
+
 size_t rh_assign_workspace_bytes(int32_t batch, int64_t n, int32_t m) {
   if (batch < 1 || n < 1 || m < 0) return 0;
-  Carver cv(nullptr);
-  cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
-  cv.take<int>(batch);
-  cv.take<int>(batch);
-  return cv.off;
+  return carve_assign(nullptr, batch, n, m).bytes;
 }
 
 int rh_assign(const float* anchors, const float* annotations, int32_t batch, int64_t n, int32_t m,
@@ -734,14 +790,15 @@ int rh_assign(const float* anchors, const float* annotations, int32_t batch, int
   RH_REQUIRE(workspace && workspace_bytes >= rh_assign_workspace_bytes(batch, n, m), RH_EWORKSPACE,
              "workspace too small: need %zu bytes", rh_assign_workspace_bytes(batch, n, m));
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
-  Carver cv(workspace);
-  LossWorkspace w{};
-  w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
-  w.gt_count = cv.take<int>(batch);
-  cv.take<int>(batch);
-  w.num_pos = num_pos;
-  return launch_assign(anchors, annotations, batch, n, m, num_classes, neg_thresh, pos_thresh, w,
-                       nullptr, state, argmax, label, iou_max, status, 1, (hipStream_t)stream);
+  const LossWorkspace w = carve_assign(workspace, batch, n, m);
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = launch_assign(anchors, annotations, batch, n, m, num_classes, neg_thresh, pos_thresh,
+                            w, nullptr, state, argmax, label, iou_max, status, s))
+    return e;
+  hipLaunchKernelGGL(sum_blk_pos_kernel, dim3(batch), dim3(kThreads), 0, s, w.blk_pos, w.nblk,
+                     num_pos);
+  RH_CHECK_LAUNCH("sum_blk_pos_kernel");
+  return RH_OK;
 }
 
 size_t rh_focal_loss_workspace_bytes(int32_t batch, int64_t n, int32_t num_classes, int32_t m) {
@@ -779,7 +836,7 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   if (stages & RH_STAGE_ASSIGN) {
     if (int e = launch_assign(anchors, annotations, batch, n, m, num_classes, params->neg_thresh,
                               params->pos_thresh, w, w.code, nullptr, nullptr, nullptr, nullptr,
-                              status, kPosStride, s))
+                              status, s))
       return e;
   }
   if (stages & RH_STAGE_STREAM) {
@@ -793,24 +850,23 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
       auto kern = u5 ? focal_stream_kernel<5> : focal_stream_kernel<4>;
       hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications,
                          d_classifications, regressions, d_regressions,
-                         reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.num_pos,
+                         reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
                          div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
-                         divisor, kPosStride);
+                         divisor);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
       hipLaunchKernelGGL(focal_rows_kernel, dim3(kGenericBlocks, batch), dim3(kThreads), 0, s,
                          classifications, d_classifications, regressions, d_regressions, anchors,
-                         w.gt, w.code, w.num_pos, w.partials, (int)n, num_classes, m, fc,
-                         params->grad_cls, params->grad_reg, divisor, kPosStride);
+                         w.gt, w.code, w.blk_pos, w.nblk, w.partials, (int)n, num_classes, m, fc,
+                         params->grad_cls, params->grad_reg, divisor);
       RH_CHECK_LAUNCH("focal_rows_kernel");
     }
   }
   if (stages & RH_STAGE_FINALIZE) {
-    float* pi = per_image ? per_image : w.per_image;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.num_pos,
-                       w.gt_count, pi, num_pos, losses, batch, (int)n, tile ? 1 : 0, kGenericBlocks,
-                       divisor, kPosStride);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
+                       w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n, tile ? 1 : 0,
+                       kGenericBlocks, divisor);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;
