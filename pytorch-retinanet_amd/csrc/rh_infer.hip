@@ -86,12 +86,18 @@ __global__ __launch_bounds__(kThreads) void clip_boxes_kernel(float4* __restrict
 // (model.py:323), kept only where it exceeds the score threshold (model.py:325).
 // Candidates are written to small per-tile lists: a tile (64 consecutive rows of the
 // flat [B*N, C] matrix) owns 64 slots and a count, so no atomics and no zeroing
-// are needed, and the scan reads the classification tensor only.
+// are needed, and the scan reads the classification tensor only.  The lists are stored
+// slot-major ([slot][tile]): a tile rarely holds more than a few candidates, so readers
+// that walk consecutive tiles find the occupied slots densely packed in a few cache lines.
 // ---------------------------------------------------------------------------
 struct TileCands {
   int* cnt;   // [num_tiles]
-  u64* key;   // [num_tiles][64]  make_key(score, global row = image*N + anchor)
-  int* lab;   // [num_tiles][64]  arg-max class
+  u64* key;   // [64][num_tiles]  make_key(score, global row = image*N + anchor)
+  int* lab;   // [64][num_tiles]  arg-max class
+  int num_tiles;
+  __device__ __forceinline__ size_t at(int tile, int slot) const {
+    return (size_t)slot * num_tiles + tile;
+  }
 };
 
 // Wave 0 of a block, lane = row of the tile; s_best[lane] = (max score, ~class) key or 0.
@@ -104,7 +110,7 @@ __device__ __forceinline__ void emit_tile(const int tile, const int rows, const 
   const bool cand = lane < rows && best != 0ull && score > thresh;
   const u64 m = __ballot(cand);
   if (cand) {
-    const size_t at = (size_t)tile * kTileRows + __popcll(m & ((1ull << lane) - 1ull));
+    const size_t at = tc.at(tile, __popcll(m & ((1ull << lane) - 1ull)));
     tc.key[at] = make_key(score, (unsigned)(row0 + lane));
     tc.lab[at] = (int)key_index(best);
   }
@@ -225,6 +231,7 @@ struct SortSrc {
   float width, height;
   const float4* boxes;
   const int* labels;
+  const float* scores;   // plain NMS: the caller's scores (the rank sort builds its keys itself)
   int N;
   int count;
   int from_tiles;
@@ -247,20 +254,19 @@ __device__ __forceinline__ int gather_image_keys(const int j, const SortSrc src,
   for (int t = t_lo + (int)threadIdx.x; t <= t_hi; t += (int)blockDim.x) {
     const int c = src.tc.cnt[t];
     if (c == 0) continue;
-    const u64* tk = src.tc.key + (size_t)t * kTileRows;
     const bool edge = t == t_lo || t == t_hi;   // such a tile also holds a neighbour image's rows
     int mine = c;
     if (edge) {
       mine = 0;
       for (int r = 0; r < c; ++r) {
-        const long long g = key_index(tk[r]);
+        const long long g = key_index(src.tc.key[src.tc.at(t, r)]);
         mine += (g >= first && g <= last);
       }
     }
     if (mine == 0) continue;
     int at = atomicAdd(s_count, mine);          // LDS counter
     for (int r = 0; r < c; ++r) {
-      const u64 k = tk[r];
+      const u64 k = src.tc.key[src.tc.at(t, r)];
       const long long g = key_index(k);
       if (!edge || (g >= first && g <= last)) {
         if (at < cap) dst[at] = k;
@@ -285,7 +291,7 @@ __device__ __forceinline__ void store_sorted(const u64 key, const int i, const i
     const int c = src.tc.cnt[t];
     int lab = 0;
     for (int r = 0; r < c; ++r)
-      if (src.tc.key[(size_t)t * kTileRows + r] == key) lab = src.tc.lab[(size_t)t * kTileRows + r];
+      if (src.tc.key[src.tc.at((int)t, r)] == key) lab = src.tc.lab[src.tc.at((int)t, r)];
     slabel[i] = lab;
   } else {
     sbox[i] = src.boxes[idx];
@@ -368,6 +374,221 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
     counters[j] = found;
     counters[batch + j] = max(found - cap, 0);
     counters[2 * batch + j] = ke;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Rank sort for candidate lists of up to kRankMax keys per image.  Keys are unique (the
+// index is part of the key), so a key's position in descending order is the number of keys
+// greater than it: no exchange network, no serial dependency, and the work spreads over the
+// whole chip instead of one workgroup per image.
+// Block (x, j) ranks 64 keys of image j.  Every block of an image first rebuilds the same
+// candidate list in LDS (tile lists compacted in tile order by a block-wide prefix sum, so
+// all blocks see one order, which is ascending anchor index), then lane l owns list entry
+// x*64 + l and each of the four waves counts the greater keys in its quarter of the list
+// (uniform addresses: LDS broadcast reads).  Because the list is in index order, "greater"
+// is a 32-bit test on the score alone: score >= mine for entries before the block's own 64,
+// score > mine for entries after them; only the block's own 64 entries need the full key.
+// The owner then decodes the box and writes (key, box, label) at its rank.
+// ---------------------------------------------------------------------------
+constexpr int kRankMax = 4096;
+constexpr int kRankKeys = 64;
+constexpr int kRankThreads = 512;
+constexpr int kRankWaves = kRankThreads / 64;
+constexpr int kRankBatch = 3;   // groups of 64 tiles whose lists a wave loads together
+constexpr int kRankSlots = 4;   // list slots per tile loaded together
+
+// mode 0: score >= mine, 1: score > mine, 2: full (score, index) key > mine
+template <int kMode>
+__device__ __forceinline__ int rank_count(const unsigned* s_sk, const unsigned* s_ix, int qa,
+                                          const int qb, const unsigned mys, const unsigned myx) {
+  int rank = 0;
+  for (; qa + 8 <= qb; qa += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned sk = s_sk[qa + u];
+      if (kMode == 0) rank += sk >= mys;
+      if (kMode == 1) rank += sk > mys;
+      if (kMode == 2) rank += (((u64)sk << 32) | s_ix[qa + u]) > (((u64)mys << 32) | myx);
+    }
+  }
+  for (; qa < qb; ++qa) {
+    const unsigned sk = s_sk[qa];
+    if (kMode == 0) rank += sk >= mys;
+    if (kMode == 1) rank += sk > mys;
+    if (kMode == 2) rank += (((u64)sk << 32) | s_ix[qa]) > (((u64)mys << 32) | myx);
+  }
+  return rank;
+}
+
+__global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
+    u64* __restrict__ keys, int* __restrict__ counters, int batch, int cap, int key_stride,
+    int topk, SortSrc src, float4* __restrict__ sbox, int* __restrict__ slabel, int box_stride) {
+  __shared__ __attribute__((aligned(16))) unsigned s_sk[kRankMax];   // score half of the keys
+  __shared__ __attribute__((aligned(16))) unsigned s_ix[kRankMax];   // index half (~index)
+  __shared__ int s_lab[kRankMax];
+  __shared__ int s_wsum[kRankWaves];
+  __shared__ int s_part[kRankWaves][kRankKeys];
+  // the image index is the fast grid dimension: blocks beyond an image's candidate count
+  // (most of the grid when the lists are far from full) are dispatched last and exit at once
+  const int j = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = blockIdx.y * kRankKeys;
+  int found;
+  if (src.from_tiles) {
+    const TileCands tc = src.tc;
+    const long long first = (long long)j * src.N, last = first + src.N - 1;
+    const int t_lo = (int)(first >> 6), t_hi = (int)(last >> 6);
+    // Wave w compacts a contiguous range of the image's tiles, 64 tiles (one per lane) at a
+    // time, so list loads are coalesced.  Loads are unconditional (tile and slot indices
+    // clamped) and issued kRankBatch x kRankSlots at a time ahead of their use: a chain of
+    // guarded, dependent loads would cost one memory latency per tile and per key.
+    // Rows of a tile are listed in ascending order, so in the image's first tile the previous
+    // image's candidates come first (skip_lo of them) and in its last tile the next image's
+    // come last.
+    const int chunk = ((t_hi - t_lo + kRankThreads) / kRankThreads) * 64;
+    const int wb = min(t_lo + wave * chunk, t_hi + 1), we = min(wb + chunk, t_hi + 1);
+    int mine = 0, skip_lo = 0;
+    for (int i0 = wb; i0 < we; i0 += 64 * kRankBatch) {
+      int c[kRankBatch];
+#pragma unroll
+      for (int u = 0; u < kRankBatch; ++u) c[u] = tc.cnt[min(i0 + u * 64 + lane, t_hi)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kRankBatch; ++u) {
+        const int t = i0 + u * 64 + lane;
+        if (t >= we) c[u] = 0;
+        if (c[u] != 0 && (t == t_lo || t == t_hi)) {
+          int m = 0, before = 0;
+          for (int r0 = 0; r0 < c[u]; r0 += 8) {
+            u64 k[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) k[r] = tc.key[tc.at(t, min(r0 + r, kTileRows - 1))];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const long long g = key_index(k[r]);
+              m += (r0 + r < c[u] && g >= first && g <= last);
+              before += (r0 + r < c[u] && g < first);
+            }
+          }
+          c[u] = m;
+          if (t == t_lo) skip_lo = before;
+        }
+        mine += c[u];
+      }
+    }
+    mine = wave_sum(mine);
+    if (lane == 0) s_wsum[wave] = mine;
+    __syncthreads();
+    int run = 0;            // list position of this wave's next entry
+    found = 0;
+#pragma unroll
+    for (int w = 0; w < kRankWaves; ++w) {
+      run += w < wave ? s_wsum[w] : 0;
+      found += s_wsum[w];
+    }
+    if (p0 >= min(found, cap) && blockIdx.y != 0) return;   // nothing to rank here (block-uniform)
+    for (int i0 = wb; i0 < we; i0 += 64 * kRankBatch) {
+      int c[kRankBatch], lo[kRankBatch], base[kRankBatch];
+#pragma unroll
+      for (int u = 0; u < kRankBatch; ++u) c[u] = tc.cnt[min(i0 + u * 64 + lane, t_hi)];
+      __builtin_amdgcn_sched_barrier(0);
+      int cm = 0;
+#pragma unroll
+      for (int u = 0; u < kRankBatch; ++u) {
+        const int t = i0 + u * 64 + lane;
+        if (t >= we) c[u] = 0;
+        lo[u] = t == t_lo ? min(skip_lo, c[u]) : 0;
+        // entries this tile adds (too many for the image's last tile, after which nothing follows)
+        const int eff = c[u] - lo[u];
+        int incl = eff;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += o;
+        }
+        base[u] = run + incl - eff;
+        run += __builtin_amdgcn_readlane(incl, 63);
+        cm = max(cm, c[u]);
+      }
+      for (int r0 = 0; __ballot(r0 < cm) != 0ull; r0 += kRankSlots) {
+        u64 k[kRankBatch][kRankSlots];
+        int l[kRankBatch][kRankSlots];
+#pragma unroll
+        for (int u = 0; u < kRankBatch; ++u) {
+          const int t = min(i0 + u * 64 + lane, t_hi);
+#pragma unroll
+          for (int r = 0; r < kRankSlots; ++r) {
+            const size_t o = tc.at(t, min(r0 + r, kTileRows - 1));
+            k[u][r] = tc.key[o];
+            l[u][r] = tc.lab[o];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kRankBatch; ++u) {
+#pragma unroll
+          for (int r = 0; r < kRankSlots; ++r) {
+            const int rr = r0 + r;
+            const long long g = key_index(k[u][r]);
+            const int pos = base[u] + rr - lo[u];
+            if (rr >= lo[u] && rr < c[u] && g <= last && pos < cap) {
+              s_sk[pos] = (unsigned)(k[u][r] >> 32);
+              s_ix[pos] = (unsigned)k[u][r];
+              s_lab[pos] = l[u][r];
+            }
+          }
+        }
+      }
+    }
+  } else {
+    found = src.count;
+    if (p0 >= min(found, cap) && blockIdx.y != 0) return;
+    for (int i = tid; i < min(found, cap); i += kRankThreads) {
+      const u64 k = make_key(src.scores[i], (unsigned)i);
+      s_sk[i] = (unsigned)(k >> 32);
+      s_ix[i] = (unsigned)k;
+      s_lab[i] = src.labels ? src.labels[i] : 0;
+    }
+  }
+  __syncthreads();
+  const int K = min(found, cap);
+  const int ke = topk > 0 ? min(K, topk) : K;
+  const int p = p0 + lane;
+  const int pc = min(p, max(K - 1, 0));
+  const unsigned mys = s_sk[pc], myx = s_ix[pc];
+  // wave w counts in [q0, q1): equal shares of the list, multiples of 8 entries
+  const int seg = ((K + 8 * kRankWaves - 1) / (8 * kRankWaves)) << 3;
+  const int q0 = min(wave * seg, K), q1 = min(q0 + seg, K);
+  int rank = rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx);
+  rank += rank_count<2>(s_sk, s_ix, max(q0, p0), min(q1, p0 + kRankKeys), mys, myx);
+  rank += rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx);
+  s_part[wave][lane] = rank;
+  __syncthreads();
+  if (wave == 0) {
+    rank = 0;
+#pragma unroll
+    for (int w = 0; w < kRankWaves; ++w) rank += s_part[w][lane];
+    if (p < K && rank < ke) {
+      const size_t o = (size_t)j * box_stride + rank;
+      keys[(size_t)j * key_stride + rank] = ((u64)mys << 32) | (u64)myx;
+      const unsigned idx = 0xFFFFFFFFu - myx;
+      if (src.from_tiles) {
+        const unsigned n = idx - (unsigned)j * (unsigned)src.N;
+        sbox[o] = clip_box(decode_box(src.anchors[n], src.reg[idx], src.bc), src.width, src.height);
+      } else {
+        sbox[o] = src.boxes[idx];
+      }
+      slabel[o] = s_lab[p];
+    }
+    if (blockIdx.y == 0 && lane == 0) {
+      counters[j] = found;
+      counters[batch + j] = max(found - cap, 0);
+      counters[2 * batch + j] = ke;
+    }
   }
 }
 
@@ -525,6 +746,10 @@ struct SweepOut {
   int* count;            // [B]
   int out_stride;
   int max_keep;          // stop after this many (<= out_stride)
+  const int* counters;   // [3][B] of the sort stage, or null
+  int* cand_out;         // [B] candidates found, or null
+  int* ovf_out;          // [B] candidates dropped for lack of room, or null
+  int batch;
 };
 
 constexpr int kSweepGroup = 8;
@@ -627,7 +852,11 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const u64* __restrict__ k
     }
     __syncthreads();   // s_kept of this group visible to the next group's loads
   }
-  if (lane == 0) o.count[j] = min(kept_total, o.max_keep);
+  if (lane == 0) {
+    o.count[j] = min(kept_total, o.max_keep);
+    if (o.cand_out) o.cand_out[j] = o.counters[j];
+    if (o.ovf_out) o.ovf_out[j] = o.counters[o.batch + j];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -698,6 +927,18 @@ static PostWorkspace carve_post(void* ws, const NmsPlan& p, long long num_tiles)
 
 static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const SortSrc& src,
                        hipStream_t s) {
+  if (p.cap <= kRankMax) {
+    hipLaunchKernelGGL(sort_rank_kernel, dim3(p.batch, (p.cap + kRankKeys - 1) / kRankKeys),
+                       dim3(kRankThreads), 0, s, w.keys, w.counters, p.batch, p.cap, p.key_stride,
+                       topk, src, w.sbox, w.slabel, p.box_cap);
+    RH_CHECK_LAUNCH("sort_rank_kernel");
+    return RH_OK;
+  }
+  if (!src.from_tiles) {
+    hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((src.count + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, s, src.scores, w.keys, src.count);
+    RH_CHECK_LAUNCH("make_keys_kernel");
+  }
   if (p.key_stride <= kLdsSortMax) {
     const size_t lds = (size_t)p.key_stride * sizeof(u64) + 16;
     if (lds > 48 * 1024)   // above the default dynamic-LDS limit the kernel must opt in
@@ -744,15 +985,6 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
                      keff, w.mask, p.key_stride, p.box_cap, p.wstride, out);
   RH_CHECK_LAUNCH("nms_sweep_kernel");
   return RH_OK;
-}
-
-__global__ __launch_bounds__(kThreads) void export_counters_kernel(const int* __restrict__ counters,
-                                                                   int* __restrict__ cnt_out,
-                                                                   int* __restrict__ ovf_out, int B) {
-  const int j = blockIdx.x * kThreads + threadIdx.x;
-  if (j >= B) return;
-  if (cnt_out) cnt_out[j] = counters[j];
-  if (ovf_out) ovf_out[j] = counters[B + j];
 }
 
 }  // namespace rh
@@ -815,10 +1047,8 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
   const PostWorkspace w = carve_post(workspace, p, 0);
-  hipLaunchKernelGGL(make_keys_kernel, dim3((unsigned)((k + kThreads - 1) / kThreads)),
-                     dim3(kThreads), 0, s, scores, w.keys, (int)k);
-  RH_CHECK_LAUNCH("make_keys_kernel");
   SortSrc src{};
+  src.scores = scores;
   src.boxes = reinterpret_cast<const float4*>(boxes);   // the caller's arrays: key index == row
   src.labels = labels;
   src.count = (int)k;
@@ -872,7 +1102,7 @@ int rh_postprocess(const float* classifications, const float* regressions, const
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const PostWorkspace w = carve_post(workspace, p, num_tiles);
-  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab};
+  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab, num_tiles};
   const int out_cap = q->max_det > 0 ? q->max_det : p.box_cap;
 
   if (stages & RH_POST_DECODE) {
@@ -910,12 +1140,11 @@ int rh_postprocess(const float* classifications, const float* regressions, const
     out.count = out_count;
     out.out_stride = out_cap;
     out.max_keep = out_cap;
+    out.counters = w.counters;
+    out.cand_out = cand_count;
+    out.ovf_out = overflow;
+    out.batch = batch;
     if (int e = launch_nms(p, w, q->iou_thresh, q->per_class, out, s)) return e;
-    if (cand_count || overflow) {
-      hipLaunchKernelGGL(export_counters_kernel, dim3((batch + kThreads - 1) / kThreads),
-                         dim3(kThreads), 0, s, w.counters, cand_count, overflow, batch);
-      RH_CHECK_LAUNCH("export_counters_kernel");
-    }
   }
   return RH_OK;
 }
