@@ -729,12 +729,19 @@ __global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __rest
 }
 
 // ---------------------------------------------------------------------------
-// Greedy sweep: one wave per image walks the sorted boxes kSweepGroup chunks of 64 at a
-// time.  Lane l of chunk c owns box c*64+l: it ANDs its predecessor words with the kept
-// bitmap of the earlier chunks (coalesced, independent loads; one ballot tells which boxes
-// are already suppressed), then the chunk's diagonal word resolves the boxes that overlap an
-// earlier box of the same chunk, one scalar step per such box.  All loads of a group are
-// issued before the first resolve, so a group costs one memory latency.
+// Greedy sweep: one workgroup of kSweepWaves waves per image walks the sorted boxes in
+// chunks of 64; wave s owns the chunks c = s, s + kSweepWaves, ...  Lane l of chunk c owns
+// box c*64+l.  A chunk is resolved in two parts:
+//   * bulk, off the critical path: AND the box's predecessor words of all earlier chunks with
+//     those chunks' kept bitmaps as they get published (the loads do not depend on anything
+//     and are issued up front, a batch at a time; the other waves resolve the chunks in
+//     between meanwhile);
+//   * tail, the serial chain: once chunk c-1 is published, one ballot tells which boxes are
+//     already suppressed, and the chunk's diagonal word resolves the boxes that overlap an
+//     earlier box of the same chunk, one scalar step per such box.
+// Kept bitmaps, running totals and the "chunks done" counter live in LDS; waves wait on the
+// counter (release / acquire at workgroup scope), never on a barrier, so each chunk costs
+// one short hand-over instead of a memory latency.
 // Outputs either the kept original indices (keep_idx, for rh_nms) or the
 // (score, label, box) triples of model.py:338-340.
 // ---------------------------------------------------------------------------
@@ -752,17 +759,25 @@ struct SweepOut {
   int batch;
 };
 
-constexpr int kSweepGroup = 8;
+constexpr int kSweepWaves = 8;
+constexpr int kSweepBatch = 32;   // predecessor words loaded together
+constexpr int kSweepSpinLimit = 1 << 22;
 
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const u64* __restrict__ keys,
-                                                       const float4* __restrict__ sbox,
-                                                       const int* __restrict__ slabel,
-                                                       const int* __restrict__ keff,
-                                                       const u64* __restrict__ mask, int key_stride,
-                                                       int box_stride, int wstride, SweepOut o) {
-  extern __shared__ __attribute__((aligned(16))) u64 s_kept[];   // kept bitmap, one word per chunk
+__host__ __device__ inline size_t sweep_lds_bytes(int wstride) {
+  return (size_t)wstride * sizeof(u64) + ((size_t)wstride + 3) * sizeof(int);
+}
+
+__global__ __launch_bounds__(64 * kSweepWaves) void nms_sweep_kernel(
+    const u64* __restrict__ keys, const float4* __restrict__ sbox, const int* __restrict__ slabel,
+    const int* __restrict__ keff, const u64* __restrict__ mask, int key_stride, int box_stride,
+    int wstride, SweepOut o) {
+  extern __shared__ __attribute__((aligned(16))) u64 s_kept[];   // [wstride] kept bitmap per chunk
+  int* s_total = reinterpret_cast<int*>(s_kept + wstride);        // [wstride + 1] kept before chunk c
+  int* s_done = s_total + wstride + 1;                            // chunks published so far
+  int* s_fail = s_done + 1;                                       // a wait gave up (never expected)
   const int j = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = keff[j];
   const int W = (K + 63) >> 6;
   const u64* kj = keys + (size_t)j * key_stride;
@@ -771,91 +786,84 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const u64* __restrict__ k
   const u64* mj = mask + (size_t)j * box_stride * wstride;
   // always-loadable label source (the keys' low words when there are no labels; value unused)
   const int* lsafe = lj ? lj : reinterpret_cast<const int*>(kj);
-  int kept_total = 0;
-  for (int c0 = 0; c0 < W && kept_total < o.max_keep; c0 += kSweepGroup) {
-    // ---- loads.  Every load is unconditional (row and word indices clamped into the written
-    // part of the mask; rows >= K are discarded by live_rows below) and issued in batches ahead
-    // of its first use: a load under a per-lane condition, or one consumed right away, costs a
-    // full memory latency each, and this wave has nothing else to hide it with.
-    u64 acc[kSweepGroup];
-    u64 inw[kSweepGroup][kSweepGroup];
-    int rowc[kSweepGroup];
-    u64 key[kSweepGroup];
-    int lab[kSweepGroup];
-    float4 box[kSweepGroup];
-#pragma unroll
-    for (int s = 0; s < kSweepGroup; ++s) {
-      rowc[s] = min((c0 + s) * 64 + lane, K - 1);
-      acc[s] = 0ull;
-#pragma unroll
-      for (int q = 0; q < kSweepGroup; ++q)
-        inw[s][q] = q <= s ? mj[(size_t)min(c0 + q, rowc[s] >> 6) * box_stride + rowc[s]] : 0ull;
-      key[s] = kj[rowc[s]];
-      lab[s] = lsafe[rowc[s]];
-      box[s] = bj[rowc[s]];
-    }
-    constexpr int kBatch = 4;   // earlier words per batch: kBatch * kSweepGroup loads in flight
-    for (int w0 = 0; w0 < c0; w0 += kBatch) {     // c0 is a multiple of kSweepGroup, hence of kBatch
-      u64 word[kBatch][kSweepGroup];
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u)
-#pragma unroll
-        for (int s = 0; s < kSweepGroup; ++s)
-          word[u][s] = mj[(size_t)(w0 + u) * box_stride + rowc[s]];
-      __builtin_amdgcn_sched_barrier(0);          // keep all loads ahead of the first use
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const u64 kw = s_kept[w0 + u];
-#pragma unroll
-        for (int s = 0; s < kSweepGroup; ++s) acc[s] |= word[u][s] & kw;
-      }
-    }
-    // ---- resolve the group's chunks in order
-    u64 kept_in[kSweepGroup];
-#pragma unroll
-    for (int s = 0; s < kSweepGroup; ++s) {
-      const int c = c0 + s;
-      kept_in[s] = 0ull;
-      if (c < W) {
-        u64 t = acc[s];
-#pragma unroll
-        for (int q = 0; q < kSweepGroup; ++q)
-          if (q < s) t |= inw[s][q] & kept_in[q];
-        const int left = K - c * 64;
-        const u64 live_rows = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-        const u64 alive = ~__ballot(t != 0ull) & live_rows;
-        const u64 diag = inw[s][s];                    // earlier boxes of this chunk that overlap me
-        u64 dep = alive & __ballot(diag != 0ull);      // their fate needs the serial walk
-        u64 kept = alive & ~dep;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        while (dep) {
-          const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(dep));
-          const u64 d = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                        (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-          if ((d & kept) == 0ull) kept |= 1ull << b;   // d only has bits below b
-          dep &= dep - 1ull;
-        }
-        kept_in[s] = kept;
-        if (lane == 0) s_kept[c] = kept;
-        if ((kept >> lane) & 1ull) {
-          const int pos = kept_total + __popcll(kept & ((1ull << lane) - 1ull));
-          if (pos < o.max_keep) {
-            const size_t at = (size_t)j * o.out_stride + pos;
-            if (o.keep_idx) o.keep_idx[at] = (long long)key_index(key[s]);
-            if (o.scores) o.scores[at] = key_score(key[s]);
-            if (o.labels) o.labels[at] = lj ? (long long)lab[s] : 0ll;
-            if (o.boxes) o.boxes[at] = box[s];
-          }
-        }
-        kept_total += __popcll(kept);
-      }
-    }
-    __syncthreads();   // s_kept of this group visible to the next group's loads
-  }
-  if (lane == 0) {
-    o.count[j] = min(kept_total, o.max_keep);
+  if (threadIdx.x == 0) {
+    s_total[0] = 0;
+    *s_done = 0;
+    *s_fail = 0;
+    if (W == 0) o.count[j] = 0;
     if (o.cand_out) o.cand_out[j] = o.counters[j];
     if (o.ovf_out) o.ovf_out[j] = o.counters[o.batch + j];
+  }
+  __syncthreads();
+  int seen = 0;   // last value of *s_done this wave has observed
+  for (int c = wave; c < W; c += kSweepWaves) {
+    // Every load is unconditional (row and word indices clamped into the written part of the
+    // mask; rows >= K are discarded by live_rows below) and issued ahead of its first use.
+    const int row = min(c * 64 + lane, K - 1);
+    const u64 diag = mj[(size_t)c * box_stride + row];   // earlier boxes of this chunk that overlap me
+    const u64 key = kj[row];
+    const int lab = lsafe[row];
+    const float4 box = bj[row];
+    u64 acc = 0ull;
+    for (int w0 = 0; w0 < c; w0 += kSweepBatch) {
+      u64 word[kSweepBatch];
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; ++u) word[u] = mj[(size_t)min(w0 + u, c) * box_stride + row];
+      __builtin_amdgcn_sched_barrier(0);          // keep all loads ahead of the first use
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; ++u) {
+        const int w = w0 + u;
+        if (w < c) {
+          // chunk w is published by another wave of this workgroup, which never waits for a
+          // later chunk, so this wait always ends; the bound only keeps a logic error from
+          // hanging the device (the image's count is then reported as -1)
+          for (int spin = 0; seen <= w; ++spin) {
+            seen = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_load(s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (seen > w) break;
+            if (spin > kSweepSpinLimit) {
+              *s_fail = 1;
+              seen = W;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          acc |= word[u] & s_kept[w];
+        }
+      }
+    }
+    const int left = K - c * 64;
+    const u64 live_rows = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    const u64 alive = ~__ballot(acc != 0ull) & live_rows;
+    u64 dep = alive & __ballot(diag != 0ull);      // their fate needs the serial walk
+    u64 kept = alive & ~dep;
+    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+    while (dep) {
+      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(dep));
+      const u64 d = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                    (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
+      if ((d & kept) == 0ull) kept |= 1ull << b;   // d only has bits below b
+      dep &= dep - 1ull;
+    }
+    const int before = s_total[c];                 // published together with chunk c-1
+    if (lane == 0) {
+      s_kept[c] = kept;
+      s_total[c + 1] = before + __popcll(kept);
+      __hip_atomic_store(s_done, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // ---- outputs, after the hand-over
+    if ((kept >> lane) & 1ull) {
+      const int pos = before + __popcll(kept & ((1ull << lane) - 1ull));
+      if (pos < o.max_keep) {
+        const size_t at = (size_t)j * o.out_stride + pos;
+        if (o.keep_idx) o.keep_idx[at] = (long long)key_index(key);
+        if (o.scores) o.scores[at] = key_score(key);
+        if (o.labels) o.labels[at] = lj ? (long long)lab : 0ll;
+        if (o.boxes) o.boxes[at] = box;
+      }
+    }
+    if (c == W - 1 && lane == 0)
+      o.count[j] = *s_fail ? -1 : min(before + __popcll(kept), o.max_keep);
   }
 }
 
@@ -975,14 +983,14 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
                      per_class ? w.slabel : nullptr, keff, w.mask, p.box_cap, p.wstride, thresh,
                      per_class);
   RH_CHECK_LAUNCH("nms_mask_kernel");
-  const size_t lds = (size_t)p.wstride * sizeof(u64);
+  const size_t lds = sweep_lds_bytes(p.wstride);
   RH_REQUIRE(lds <= 160 * 1024, RH_ESHAPE, "%d boxes per image exceed the sweep's LDS bitmap",
              p.box_cap);
   if (lds > 48 * 1024)
     RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(p.batch), dim3(64), lds, s, w.keys, w.sbox, w.slabel,
-                     keff, w.mask, p.key_stride, p.box_cap, p.wstride, out);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(p.batch), dim3(64 * kSweepWaves), lds, s, w.keys, w.sbox,
+                     w.slabel, keff, w.mask, p.key_stride, p.box_cap, p.wstride, out);
   RH_CHECK_LAUNCH("nms_sweep_kernel");
   return RH_OK;
 }

@@ -326,7 +326,10 @@ def nms(boxes, scores, iou_threshold, labels: Optional[torch.Tensor] = None):
     with torch.cuda.device(dev):
         _lib.check(lib.rh_nms(_p(b), _p(s), _p(lab), k, float(iou_threshold), _p(keep), _p(count),
                               _p(ws), ws.numel(), _stream(dev)), "rh_nms")
-    return keep[: int(count.item())]
+    kept = int(count.item())
+    if kept < 0:
+        raise _lib.RetinaHeadError("NMS sweep gave up waiting inside a workgroup (internal error)")
+    return keep[:kept]
 
 
 def postprocess_raw(classifications, regressions, anchors_t, height, width, score_thresh=0.05,

@@ -243,6 +243,8 @@ def postprocess(classification, regression, anchors, img_batch, score_thresh=0.0
             break
         cap = min(n, int(counts[1].max()))
     kept = counts[0].tolist()
+    if min(kept) < 0:
+        raise RetinaHeadError("NMS sweep gave up waiting inside a workgroup (internal error)")
     if output == "tuple":
         k = kept[0]
         return [out["scores"][0, :k], out["labels"][0, :k], out["boxes"][0, :k]]
