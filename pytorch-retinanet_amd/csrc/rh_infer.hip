@@ -650,7 +650,7 @@ __device__ __forceinline__ bool nms_hit_exact(const float inter, const float den
   return inter / denom > thresh;
 }
 
-__global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __restrict__ sbox,
+__global__ __launch_bounds__(kThreads) void nms_mask_general_kernel(const float4* __restrict__ sbox,
                                                             const int* __restrict__ slabel,
                                                             const int* __restrict__ keff,
                                                             u64* __restrict__ mask, int box_stride,
@@ -714,6 +714,121 @@ __global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __rest
     }
     sure &= allowed;
     unsure &= allowed;
+    while (unsure) {                      // rare: exact division for the pairs inside the band
+      const int cc = __builtin_ctzll(unsure);
+      unsure &= unsure - 1ull;
+      const float4 b = s_box[wave][cc];
+      const float w = fmaxf(0.0f, fminf(mine.z, b.z) - fmaxf(mine.x, b.x));
+      const float h = fmaxf(0.0f, fminf(mine.w, b.w) - fmaxf(mine.y, b.y));
+      const float inter = w * h;
+      if (nms_hit_exact(inter, (area + s_area[wave][cc]) - inter, thresh)) sure |= 1ull << cc;
+    }
+    if (i < K) mj[(size_t)rt * box_stride + i] = sure;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The same bitmask for 0 < thresh, in as few vector instructions per pair as the test allows
+// (the mask stage is bound by vector ALU throughput, not by memory):
+//   w = min(x2, X2) - max(x1, X1); h likewise; inter = max(w, 0) * h   (h <= 0 gives inter <= 0)
+//   denom = max((area + AREA) - inter, 0)
+//   sure     = inter > denom * (thresh * (1 + 2^-21))   -> IoU > thresh for certain
+//   possible = inter > denom * (thresh * (1 - 2^-21))   -> cannot be excluded
+// inter > 0 implies both boxes have positive width and height and denom >= inter > 0, so the
+// clamp of denom only matters for degenerate boxes, where it makes both tests fail as they
+// must (IoU is then 0 or NaN).  possible & ~sure (a 2^-20 relative band around the threshold)
+// is settled afterwards with the exact division.  min / max are issued as single
+// instructions: the compiler would wrap each in NaN-quieting moves, more than doubling the
+// count.  Each test shifts its result into the lane's word through the carry
+// (word = 2 * word + test), walking the 32 boxes of a half-word from the highest down.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float vmin(const float a, const float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(const float a, const float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax0(const float a) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+// word = 2 * word + (a > b)
+__device__ __forceinline__ void shift_in_gt(unsigned& word, const float a, const float b) {
+  asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+      : "+v"(word)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+
+template <bool kPerClass>
+__global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __restrict__ sbox,
+                                                            const int* __restrict__ slabel,
+                                                            const int* __restrict__ keff,
+                                                            u64* __restrict__ mask, int box_stride,
+                                                            int wstride, float thresh) {
+  __shared__ float4 s_box[kThreads / 64][64];
+  __shared__ float s_area[kThreads / 64][64];
+  __shared__ int s_lab[kThreads / 64][64];
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = keff[j];
+  const int W = (K + 63) >> 6;
+  const long long T = (long long)W * (W + 1) / 2;
+  const float4* bj = sbox + (size_t)j * box_stride;
+  const int* lj = kPerClass ? slabel + (size_t)j * box_stride : nullptr;
+  u64* mj = mask + (size_t)j * box_stride * wstride;
+  const float c_hi = thresh * (1.0f + 4.8e-7f), c_lo = thresh * (1.0f - 4.8e-7f);
+  for (long long id = (long long)blockIdx.x * (kThreads / 64) + wave; id < T;
+       id += (long long)gridDim.x * (kThreads / 64)) {
+    // tile id -> (rt, ct) with rt <= ct; row rt of the triangle starts at rt*W - rt*(rt-1)/2
+    int rt = (int)(((2.0 * W + 1.0) - sqrt((2.0 * W + 1.0) * (2.0 * W + 1.0) - 8.0 * (double)id)) * 0.5);
+    rt = max(0, min(rt, W - 1));
+    while (rt > 0 && (long long)rt * W - (long long)rt * (rt - 1) / 2 > id) --rt;
+    while ((long long)(rt + 1) * W - (long long)(rt + 1) * rt / 2 <= id) ++rt;
+    const int ct = rt + (int)(id - ((long long)rt * W - (long long)rt * (rt - 1) / 2));
+    const int i = ct * 64 + lane;       // my box (the later one)
+    const int e = rt * 64 + lane;       // the earlier box this lane stages
+    const float4 mine = bj[min(i, K - 1)];
+    const int mylab = kPerClass ? lj[min(i, K - 1)] : 0;
+    {
+      const float4 eb = bj[min(e, K - 1)];
+      s_box[wave][lane] = eb;
+      s_area[wave][lane] = (eb.z - eb.x) * (eb.w - eb.y);
+      if (kPerClass) s_lab[wave][lane] = lj[min(e, K - 1)];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed
+    const float area = (mine.z - mine.x) * (mine.w - mine.y);
+    const int emax = min(64, K - rt * 64);
+    // earlier boxes only: bits below my own position in the diagonal tile, all bits otherwise
+    const u64 allowed = (rt == ct ? ((1ull << lane) - 1ull) : ~0ull) &
+                        (emax >= 64 ? ~0ull : ((1ull << emax) - 1ull));
+    unsigned sure_w[2], poss_w[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      unsigned sw = 0u, pw = 0u;
+#pragma unroll 8
+      for (int cc = half * 32 + 31; cc >= half * 32; --cc) {
+        const float4 b = s_box[wave][cc];
+        const float w = vmin(mine.z, b.z) - vmax(mine.x, b.x);
+        const float h = vmin(mine.w, b.w) - vmax(mine.y, b.y);
+        float inter = vmax0(w) * h;
+        if (kPerClass) inter = s_lab[wave][cc] == mylab ? inter : -1.0f;
+        const float denom = vmax0((area + s_area[wave][cc]) - inter);
+        shift_in_gt(sw, inter, denom * c_hi);
+        shift_in_gt(pw, inter, denom * c_lo);
+      }
+      sure_w[half] = sw;
+      poss_w[half] = pw;
+    }
+    u64 sure = (((u64)sure_w[1] << 32) | sure_w[0]) & allowed;
+    u64 unsure = (((u64)poss_w[1] << 32) | poss_w[0]) & allowed & ~sure;
     while (unsure) {                      // rare: exact division for the pairs inside the band
       const int cc = __builtin_ctzll(unsure);
       unsure &= unsure - 1ull;
@@ -979,9 +1094,15 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
   long long gx = (tiles + 3) / 4;
   if (gx > 2048) gx = 2048;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)gx, p.batch), dim3(kThreads), 0, s, w.sbox,
-                     per_class ? w.slabel : nullptr, keff, w.mask, p.box_cap, p.wstride, thresh,
-                     per_class);
+  if (thresh > 0.0f && thresh < 1e30f) {
+    auto kern = per_class ? nms_mask_kernel<true> : nms_mask_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, p.batch), dim3(kThreads), 0, s, w.sbox,
+                       per_class ? w.slabel : nullptr, keff, w.mask, p.box_cap, p.wstride, thresh);
+  } else {
+    hipLaunchKernelGGL(nms_mask_general_kernel, dim3((unsigned)gx, p.batch), dim3(kThreads), 0, s,
+                       w.sbox, per_class ? w.slabel : nullptr, keff, w.mask, p.box_cap, p.wstride,
+                       thresh, per_class);
+  }
   RH_CHECK_LAUNCH("nms_mask_kernel");
   const size_t lds = sweep_lds_bytes(p.wstride);
   RH_REQUIRE(lds <= 160 * 1024, RH_ESHAPE, "%d boxes per image exceed the sweep's LDS bitmap",
