@@ -853,7 +853,7 @@ __global__ __launch_bounds__(kThreads) void nms_mask_kernel(const float4* __rest
 //     between meanwhile);
 //   * tail, the serial chain: once chunk c-1 is published, one ballot tells which boxes are
 //     already suppressed, and the chunk's diagonal word resolves the boxes that overlap an
-//     earlier box of the same chunk, one scalar step per such box.
+//     earlier box of the same chunk.
 // Kept bitmaps, running totals and the "chunks done" counter live in LDS; waves wait on the
 // counter (release / acquire at workgroup scope), never on a barrier, so each chunk costs
 // one short hand-over instead of a memory latency.
@@ -874,12 +874,31 @@ struct SweepOut {
   int batch;
 };
 
-constexpr int kSweepWaves = 8;
+constexpr int kSweepWaves = 16;
 constexpr int kSweepBatch = 32;   // predecessor words loaded together
 constexpr int kSweepSpinLimit = 1 << 22;
 
 __host__ __device__ inline size_t sweep_lds_bytes(int wstride) {
   return (size_t)wstride * sizeof(u64) + ((size_t)wstride + 3) * sizeof(int);
+}
+
+// Waits until chunk w of this image is published (*s_done > w); `seen` caches the last value
+// read.  Chunk w is published by another wave of this workgroup, which never waits for a
+// later chunk, so the wait always ends; the bound only keeps a logic error from hanging the
+// device (the image's count is then reported as -1).
+__device__ __forceinline__ void wait_published(int* s_done, int* s_fail, const int w, const int W,
+                                               int& seen) {
+  for (int spin = 0; seen <= w; ++spin) {
+    seen = __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (seen > w) break;
+    if (spin > kSweepSpinLimit) {
+      *s_fail = 1;
+      seen = W;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
 }
 
 __global__ __launch_bounds__(64 * kSweepWaves) void nms_sweep_kernel(
@@ -919,47 +938,58 @@ __global__ __launch_bounds__(64 * kSweepWaves) void nms_sweep_kernel(
     const u64 key = kj[row];
     const int lab = lsafe[row];
     const float4 box = bj[row];
+    // the two chunks right before mine are published last: their words get registers of
+    // their own, so the hand-over path below does not run through the unrolled chain
+    const u64 last1 = mj[(size_t)max(c - 1, 0) * box_stride + row];
+    const u64 last2 = mj[(size_t)max(c - 2, 0) * box_stride + row];
     u64 acc = 0ull;
-    for (int w0 = 0; w0 < c; w0 += kSweepBatch) {
+    const int cb = c - 2;   // chunks [0, cb) go through the batches
+    for (int w0 = 0; w0 < cb; w0 += kSweepBatch) {
       u64 word[kSweepBatch];
 #pragma unroll
       for (int u = 0; u < kSweepBatch; ++u) word[u] = mj[(size_t)min(w0 + u, c) * box_stride + row];
       __builtin_amdgcn_sched_barrier(0);          // keep all loads ahead of the first use
+      // words of chunks already published: plain LDS reads, no waiting in between
+      seen = max(seen, __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                           s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)));
+      const int ready = min(seen, cb);
+#pragma unroll
+      for (int u = 0; u < kSweepBatch; ++u)
+        if (w0 + u < ready) acc |= word[u] & s_kept[w0 + u];
+      // the rest as they get published
 #pragma unroll
       for (int u = 0; u < kSweepBatch; ++u) {
         const int w = w0 + u;
-        if (w < c) {
-          // chunk w is published by another wave of this workgroup, which never waits for a
-          // later chunk, so this wait always ends; the bound only keeps a logic error from
-          // hanging the device (the image's count is then reported as -1)
-          for (int spin = 0; seen <= w; ++spin) {
-            seen = __builtin_amdgcn_readfirstlane(
-                __hip_atomic_load(s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (seen > w) break;
-            if (spin > kSweepSpinLimit) {
-              *s_fail = 1;
-              seen = W;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
+        if (w >= ready && w < cb) {
+          wait_published(s_done, s_fail, w, W, seen);
           acc |= word[u] & s_kept[w];
         }
       }
     }
+    if (c >= 2) {
+      wait_published(s_done, s_fail, c - 2, W, seen);
+      acc |= last2 & s_kept[c - 2];
+    }
+    if (c >= 1) {
+      wait_published(s_done, s_fail, c - 1, W, seen);
+      acc |= last1 & s_kept[c - 1];
+    }
     const int left = K - c * 64;
     const u64 live_rows = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
     const u64 alive = ~__ballot(acc != 0ull) & live_rows;
-    u64 dep = alive & __ballot(diag != 0ull);      // their fate needs the serial walk
-    u64 kept = alive & ~dep;
-    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-    while (dep) {
-      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(dep));
-      const u64 d = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                    (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-      if ((d & kept) == 0ull) kept |= 1ull << b;   // d only has bits below b
-      dep &= dep - 1ull;
+    // Inside the chunk a box is dropped iff an earlier KEPT box of the chunk overlaps it.
+    // Bracket the kept set between `lo` (surely kept) and `hi` (possibly kept) and tighten
+    // both with one ballot each until they meet; every round settles at least the first open
+    // box, and in practice the chains are a few boxes deep, so this takes 2-4 rounds instead
+    // of one scalar step per overlapping box.
+    u64 lo = alive & ~__ballot(diag != 0ull), hi = alive;
+    while (lo != hi) {
+      const u64 nlo = alive & ~__ballot((diag & hi) != 0ull);
+      const u64 nhi = alive & ~__ballot((diag & lo) != 0ull);
+      lo = nlo;
+      hi = nhi;
     }
+    const u64 kept = lo;
     const int before = s_total[c];                 // published together with chunk c-1
     if (lane == 0) {
       s_kept[c] = kept;
