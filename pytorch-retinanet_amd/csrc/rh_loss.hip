@@ -101,9 +101,12 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
   int lab0 = -1;      // label of the image's first valid GT (arg-max of an all-zero IoU row)
   for (int m0 = 0; m0 < M; m0 += kGtChunk) {
     // ---- stage: one annotation row per thread, keep the valid ones, in order
+    // (all five values of the row are loaded up front, row index clamped: one memory latency
+    // instead of a label load followed by a dependent box load)
     const int m = m0 + (int)threadIdx.x;
-    float lab = -1.0f;
-    if (m < M) lab = aj[m * 5 + 4];
+    const int mc = min(m, M - 1);
+    const float rx1 = aj[mc * 5 + 0], ry1 = aj[mc * 5 + 1], rx2 = aj[mc * 5 + 2],
+                ry2 = aj[mc * 5 + 3], lab = aj[mc * 5 + 4];
     const bool valid = m < M && lab != -1.0f;
     const unsigned long long vm = __ballot(valid);
     __syncthreads();                       // previous chunk's readers are done
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     }
     if (valid) {
       GtRec r;
-      r.x1 = aj[m * 5 + 0];
-      r.y1 = aj[m * 5 + 1];
-      r.x2 = aj[m * 5 + 2];
-      r.y2 = aj[m * 5 + 3];
+      r.x1 = rx1;
+      r.y1 = ry1;
+      r.x2 = rx2;
+      r.y2 = ry2;
       r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
       int l = (int)lab;
       if (!(lab > -1.0f && lab < (float)C)) {   // also catches NaN
