@@ -133,6 +133,10 @@ typedef struct rh_focal_params {
   float grad_cls;       /* upstream gradient of classification_loss */
   float grad_reg;       /* upstream gradient of regression_loss     */
   int32_t batch_divisor;
+  int32_t from_logits;  /* 0: classifications are probabilities, the reference's signature.
+                           1: they are logits; the head's nn.Sigmoid (model.py:177, 193) is folded
+                           into the stream, d_classifications is the gradient with respect to the
+                           logits (dL/dp * p * (1 - p), as autograd through torch.sigmoid). */
 } rh_focal_params;
 
 void rh_focal_params_default(rh_focal_params* p);

@@ -200,8 +200,17 @@ def _box_targets(anchors, gt_boxes):
     return (t / np.array([0.1, 0.1, 0.2, 0.2], dtype=F32)[None, :]).astype(F32)
 
 
+def sigmoid_f32(x):
+    """float32 sigmoid as torch.sigmoid evaluates it, 1 / (1 + exp(-x)): the head's output
+    activation, models/retinanet/model.py:177, 193."""
+    x = np.asarray(x, dtype=F32)
+    with np.errstate(over="ignore"):
+        return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
+
+
 def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
-                       alpha=0.25, grad_cls=1.0, grad_reg=1.0, batch_divisor=None):
+                       alpha=0.25, grad_cls=1.0, grad_reg=1.0, batch_divisor=None,
+                       from_logits=False):
     """Losses and gradients for a batch (gamma is 2 as in losses.py:31).
 
     Returns dict with
@@ -212,7 +221,13 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
         grad_cls*classification_loss + grad_reg*regression_loss.
     ``batch_divisor`` (default B) is the number of images the mean runs over;
     data-parallel shards pass the global batch size.
+    ``from_logits``: classifications are the head's logits; the sigmoid of model.py:177,193
+    is applied first and d_classifications is the gradient with respect to the logits
+    (chain rule through the sigmoid, dp/dx = p (1 - p), as autograd applies it).
     """
+    logits_in = bool(from_logits)
+    if logits_in:
+        classifications = sigmoid_f32(classifications)
     cls = np.asarray(classifications, dtype=F32)
     reg = np.asarray(regressions, dtype=F32)
     anc = np.asarray(anchors, dtype=F32).reshape(-1, 4)
@@ -233,6 +248,8 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
         norm = F32(max(asg["num_pos"], 1))
         cls_img[j] = F32(loss.sum(dtype=np.float64)) / norm     # losses.py:94
         d_cls[j] = grad * (F32(grad_cls) / (norm * F32(div)))
+        if logits_in:
+            d_cls[j] = d_cls[j] * ((F32(1) - cls[j]) * cls[j])
         pos = asg["state"] == STATE_POSITIVE
         if asg["num_pos"] > 0:                                  # losses.py:98-134
             gt = valid_gt(ann[j])

@@ -35,6 +35,7 @@ void rh_focal_params_default(rh_focal_params* p) {
   p->grad_cls = 1.0f;
   p->grad_reg = 1.0f;
   p->batch_divisor = 0;
+  p->from_logits = 0;
 }
 
 void rh_anchor_cfg_default(rh_anchor_cfg* cfg) {

@@ -310,6 +310,44 @@ __device__ __forceinline__ float focal_any(const float p, const bool one, const 
   return focal_core(p, pc, one ? q : pc, one ? pc : q, -a * kLn2, (one ? a : -a) * scale, grad);
 }
 
+// Logits-in mode: the head's nn.Sigmoid (model.py:177, 193) is folded into the stream.  The
+// element is a logit x; p = 1 / (1 + exp(-x)) in float32, the loss is the probability-mode
+// loss of p and the gradient flows through the sigmoid as autograd does it:
+// dL/dx = dL/dp * p * (1 - p).
+// The stream has room for about a dozen more vector instructions per element before it
+// stops being bound by HBM, so exp is the hardware exp2 (1 ulp; the rounding of x * log2(e)
+// adds |x| * 4e-8 relative, far inside the 1e-5 bar) and the division is the hardware
+// reciprocal plus one Newton step.  The step matters: 1 - p is exact given p, so for p close
+// to 1 the last bit of p decides several digits of the gradient, and a plain 1-ulp reciprocal
+// would show there.  exp2 is capped so that 1 + e stays finite for the Newton step.
+__device__ __forceinline__ float sigmoid_f32(const float x) {
+  const float e = fminf(__builtin_amdgcn_exp2f(x * -1.442695040888963f), 1e30f);
+  const float d = 1.0f + e;
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+
+template <bool kLogits>
+__device__ __forceinline__ float focal_zero_in(const float x, const FocalConst k, const float k0l,
+                                               const float k0g, float& grad) {
+  if (!kLogits) return focal_zero(x, k, k0l, k0g, grad);
+  const float p = sigmoid_f32(x);
+  float gp;
+  const float l = focal_zero(p, k, k0l, k0g, gp);
+  grad = gp * ((1.0f - p) * p);
+  return l;
+}
+template <bool kLogits>
+__device__ __forceinline__ float focal_any_in(const float x, const bool one, const FocalConst k,
+                                              const float scale, float& grad) {
+  if (!kLogits) return focal_any(x, one, k, scale, grad);
+  const float p = sigmoid_f32(x);
+  float gp;
+  const float l = focal_any(p, one, k, scale, gp);
+  grad = gp * ((1.0f - p) * p);
+  return l;
+}
+
 // Smooth-L1 of one regression coordinate of a positive anchor (losses.py:101-133).
 // k = 0..3 selects dx, dy, dw, dh.  Returns the loss; *grad = d loss / d regression.
 __device__ __forceinline__ float smooth_l1_coord(const int k, const float4 a, const GtRec r,
@@ -356,7 +394,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // Requirements checked on the host: 4 <= C < 8192, N >= 64, all pointers 16-byte
 // aligned, B*N < 2^31.
 // ---------------------------------------------------------------------------
-template <int U>
+template <int U, bool kLogits>
 __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
@@ -448,10 +486,10 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
           const int v = v0 + u * kThreads;
           if (v < nvec) {
             float g0, g1, g2, g3;
-            cl0 += focal_zero(val[u].x, fc, k0l, k0g, g0);
-            cl0 += focal_zero(val[u].y, fc, k0l, k0g, g1);
-            cl0 += focal_zero(val[u].z, fc, k0l, k0g, g2);
-            cl0 += focal_zero(val[u].w, fc, k0l, k0g, g3);
+            cl0 += focal_zero_in<kLogits>(val[u].x, fc, k0l, k0g, g0);
+            cl0 += focal_zero_in<kLogits>(val[u].y, fc, k0l, k0g, g1);
+            cl0 += focal_zero_in<kLogits>(val[u].z, fc, k0l, k0g, g2);
+            cl0 += focal_zero_in<kLogits>(val[u].w, fc, k0l, k0g, g3);
             v4f o;
             o.x = g0; o.y = g1; o.z = g2; o.w = g3;
             __builtin_nontemporal_store(o, &d4[v]);
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
               const bool second = r >= split;
               const bool live = cd != kCodeIgn;
               float g;
-              float l = focal_any(in[e], one, fc, second ? sc1 : sc0, g);
+              float l = focal_any_in<kLogits>(in[e], one, fc, second ? sc1 : sc0, g);
               l = live ? l : 0.f;
               out[e] = live ? g : 0.f;
               cl0 += second ? 0.f : l;
@@ -511,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
         const bool second = r >= split;
         const bool live = cd != kCodeIgn;
         float g;
-        float l = focal_any(prob[base + x], one, fc, second ? sc1 : sc0, g);
+        float l = focal_any_in<kLogits>(prob[base + x], one, fc, second ? sc1 : sc0, g);
         dprob[base + x] = live ? g : 0.f;
         l = live ? l : 0.f;
         cl0 += second ? 0.f : l;
@@ -541,6 +579,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
 // not take (C < 4, C >= 8192, N < 64, unaligned tensors).
 // partials layout: [B][kGenericBlocks][2] (classification, regression).
 // ---------------------------------------------------------------------------
+template <bool kLogits>
 __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float* __restrict__ anchors, const GtRec* __restrict__ gt,
@@ -564,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
     float* d = dprob + row * C;
     for (int c = lane; c < C; c += 64) {
       float g;
-      const float l = focal_any(p[c], cd >= 0 && (cd & 0xFFFF) == c, fc, sc, g);
+      const float l = focal_any_in<kLogits>(p[c], cd >= 0 && (cd & 0xFFFF) == c, fc, sc, g);
       d[c] = live ? g : 0.f;
       cl += live ? l : 0.f;
     }
@@ -850,7 +889,9 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
       // One tile per workgroup: the hardware dispatcher balances the 17k+ tiles better than a
       // grid-stride loop did (measured 125 us against 142 us at B=16, N=69354, C=80), and
       // non-temporal loads and stores (the data is touched once) were worth another 8 %.
-      auto kern = u5 ? focal_stream_kernel<5> : focal_stream_kernel<4>;
+      auto kern = params->from_logits
+                      ? (u5 ? focal_stream_kernel<5, true> : focal_stream_kernel<4, true>)
+                      : (u5 ? focal_stream_kernel<5, false> : focal_stream_kernel<4, false>);
       hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications,
                          d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
@@ -859,7 +900,8 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                          divisor);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
-      hipLaunchKernelGGL(focal_rows_kernel, dim3(kGenericBlocks, batch), dim3(kThreads), 0, s,
+      auto kern = params->from_logits ? focal_rows_kernel<true> : focal_rows_kernel<false>;
+      hipLaunchKernelGGL(kern, dim3(kGenericBlocks, batch), dim3(kThreads), 0, s,
                          classifications, d_classifications, regressions, d_regressions, anchors,
                          w.gt, w.code, w.blk_pos, w.nblk, w.partials, (int)n, num_classes, m, fc,
                          params->grad_cls, params->grad_reg, divisor);

@@ -41,6 +41,7 @@ class FocalParams(C.Structure):
         ("grad_cls", C.c_float),
         ("grad_reg", C.c_float),
         ("batch_divisor", C.c_int32),
+        ("from_logits", C.c_int32),
     ]
 
 

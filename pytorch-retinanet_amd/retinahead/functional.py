@@ -193,7 +193,7 @@ _ws_bytes_cache = {}
 
 def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alpha=0.25,
                        neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
-                       batch_divisor=0, stages=_lib.STAGE_ALL, out=None):
+                       batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False):
     """Runs the fused loss kernels.  Returns a dict of device tensors:
     losses [2], per_image [2,B], num_pos [B], status [B], d_classifications, d_regressions.
     ``out`` may carry buffers from an earlier call (used when stages are run one at a time).
@@ -222,7 +222,7 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
             d_regressions=torch.empty_like(reg),
         )
     params = _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
-                              float(grad_reg), int(batch_divisor))
+                              float(grad_reg), int(batch_divisor), int(bool(from_logits)))
     shape_key = (bsz, n, c, m)
     need = _ws_bytes_cache.get(shape_key)
     if need is None:

@@ -30,7 +30,7 @@ class _DenseHeadLossFn(torch.autograd.Function):
             classifications, regressions, anchors, annotations, alpha=cfg["alpha"],
             neg_thresh=cfg["neg_thresh"], pos_thresh=cfg["pos_thresh"],
             grad_cls=cfg["expected_grad"], grad_reg=cfg["expected_grad"],
-            batch_divisor=cfg["batch_divisor"])
+            batch_divisor=cfg["batch_divisor"], from_logits=cfg["from_logits"])
         ctx.d_cls = out["d_classifications"]
         ctx.d_reg = out["d_regressions"]
         ctx.expected = cfg["expected_grad"]
@@ -75,14 +75,19 @@ class FocalLoss(nn.Module):
     check_labels: read the device status word after the call (one host
         synchronisation) and raise IndexError for a label outside [0, C), as
         losses.py:79 does.
+    from_logits: ``classifications`` holds the head's logits instead of probabilities:
+        the ``nn.Sigmoid`` of models/retinanet/model.py:177,193 is folded into the loss
+        kernel (same loss; the gradient is the one autograd gives through
+        ``torch.sigmoid``), which saves the head a full read and write of the [B,N,C]
+        tensor in each direction.
     """
 
     def __init__(self, alpha=0.25, neg_thresh=0.4, pos_thresh=0.5, expected_grad=1.0,
-                 batch_divisor=0, check_labels=False):
+                 batch_divisor=0, check_labels=False, from_logits=False):
         super().__init__()
         self.cfg = dict(alpha=float(alpha), neg_thresh=float(neg_thresh),
                         pos_thresh=float(pos_thresh), expected_grad=float(expected_grad),
-                        batch_divisor=int(batch_divisor), last=None)
+                        batch_divisor=int(batch_divisor), from_logits=bool(from_logits), last=None)
         self.check_labels = bool(check_labels)
 
     @property

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, logits_grad_close
 from oracle import dense_head_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -141,6 +141,45 @@ def test_loss_vs_oracle(rh, bsz, size, c, m, valid):
     assert np.allclose(pi[1], ref["reg_per_image"], rtol=RTOL, atol=0)
     grad_close(out["d_classifications"].cpu().numpy(), ref["d_classifications"])
     grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+
+
+@pytest.mark.parametrize("case", ["normal", "c80", "extreme"])
+def test_loss_on_logits_golden(rh, focal_logits_golden, case):
+    """from_logits=True against the reference fed torch.sigmoid(logits)."""
+    d = focal_logits_golden[case]
+    cls = dev(d["cls"]).requires_grad_(True)
+    reg = dev(d["reg"]).requires_grad_(True)
+    out = rh.FocalLoss(from_logits=True)(cls, reg, dev(d["anchors"]), dev(d["ann"]))
+    total = float(d["g"][0]) * out["classification_loss"].sum() + float(d["g"][1]) * out["regression_loss"].sum()
+    total.backward()
+    assert np.allclose(out["classification_loss"].detach().cpu().numpy(), d["cls_loss"], rtol=RTOL, atol=0)
+    assert np.allclose(out["regression_loss"].detach().cpu().numpy(), d["reg_loss"], rtol=RTOL, atol=0)
+    logits_grad_close(cls.grad.cpu().numpy(), d["d_cls"], d["cls"])
+    grad_close(reg.grad.cpu().numpy(), d["d_reg"], atol_rel=REG_ATOL_REL)
+
+
+@pytest.mark.parametrize("bsz,size,c,m,valid", [
+    (3, 256, 80, 8, [8, 0, 3]),
+    (2, 96, 5, 4, [4, 1]),           # C not a multiple of 4
+    (1, 64, 3, 4, [3]),              # generic row kernel
+])
+def test_loss_on_logits_vs_oracle_and_probability_mode(rh, bsz, size, c, m, valid):
+    rng = np.random.default_rng(70 + c)
+    _, reg, anc, ann = make_batch(7 + c, bsz, size, c, m, valid)
+    x = rng.normal(-4.595, 2.0, (bsz, anc.shape[1], c)).astype(np.float32)
+    x[0, :50, 0] = np.linspace(5.0, 9.5, 50, dtype=np.float32)      # p close to 1 and over the clamp
+    ref = O.focal_loss_fwd_bwd(x, reg, anc, ann, from_logits=True)
+    out = rh.functional.focal_loss_fwd_bwd(dev(x), dev(reg), dev(anc), dev(ann), from_logits=True)
+    assert np.array_equal(out["num_pos"].cpu().numpy(), ref["num_pos"])
+    assert np.allclose(out["losses"].cpu().numpy(),
+                       [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
+    logits_grad_close(out["d_classifications"].cpu().numpy(), ref["d_classifications"], x)
+    grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+    # the same loss as the probability signature applied to torch.sigmoid of the logits
+    xs = dev(x)
+    prob = rh.functional.focal_loss_fwd_bwd(torch.sigmoid(xs), dev(reg), dev(anc), dev(ann))
+    assert np.allclose(out["losses"].cpu().numpy(), prob["losses"].cpu().numpy(), rtol=RTOL, atol=0)
+    assert torch.equal(out["d_regressions"], prob["d_regressions"])
 
 
 def test_loss_deterministic_and_unaligned(rh):

@@ -4,7 +4,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden
+from conftest import golden_cases, load_golden, logits_grad_close
 from oracle import dense_head_oracle as O
 
 RTOL = 1e-5          # losses and gradients: 1e-5 relative (fp32)
@@ -66,6 +66,20 @@ def test_focal_loss_matches_reference(focal_golden, case):
     assert np.allclose(out["regression_loss"], d["reg_loss"], rtol=RTOL, atol=0)
     assert out["classification_loss"].shape == (1,) and out["regression_loss"].shape == (1,)
     grad_close(out["d_classifications"], d["d_cls"])
+    grad_close(out["d_regressions"], d["d_reg"])
+
+
+@pytest.mark.parametrize("case", ["normal", "c80", "extreme"])
+def test_focal_loss_on_logits_matches_reference(focal_logits_golden, case):
+    """Fixtures: the reference loss fed torch.sigmoid(logits) (what the head does, model.py:177,193),
+    gradients taken with respect to the logits."""
+    d = focal_logits_golden[case]
+    out = O.focal_loss_fwd_bwd(d["cls"], d["reg"], d["anchors"], d["ann"], grad_cls=float(d["g"][0]),
+                               grad_reg=float(d["g"][1]), from_logits=True)
+    assert np.array_equal(out["num_pos"], d["num_pos"])
+    assert np.allclose(out["classification_loss"], d["cls_loss"], rtol=RTOL, atol=0)
+    assert np.allclose(out["regression_loss"], d["reg_loss"], rtol=RTOL, atol=0)
+    logits_grad_close(out["d_classifications"], d["d_cls"], d["cls"])
     grad_close(out["d_regressions"], d["d_reg"])
 
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--cfg", type=int, default=2)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--infer", action="store_true")
+    ap.add_argument("--logits", action="store_true", help="loss on logits (sigmoid folded in)")
     a = ap.parse_args()
     bsz, size, c, m = CFG[a.cfg]
     dev = torch.device("cuda:0")
@@ -34,12 +35,15 @@ def main():
         if a.cfg == 4:   # every row valid
             pass
         cls, reg, ann = (torch.from_numpy(x).to(dev) for x in (cls_np, reg_np, ann_np))
-        bufs = F.focal_loss_fwd_bwd(cls, reg, anchors, ann)
+        if a.logits:
+            cls = torch.logit(cls.double()).float().contiguous()
+        bufs = F.focal_loss_fwd_bwd(cls, reg, anchors, ann, from_logits=a.logits)
         print("num_pos", bufs["num_pos"].cpu().numpy().tolist())
         algo = bsz * n * (8 * c + 48)
         for name, st in (("assign", _lib.STAGE_ASSIGN), ("stream", _lib.STAGE_STREAM),
                          ("finalize", _lib.STAGE_FINALIZE), ("all", _lib.STAGE_ALL)):
-            fn = lambda: F.focal_loss_fwd_bwd(cls, reg, anchors, ann, stages=st, out=bufs)
+            fn = lambda: F.focal_loss_fwd_bwd(cls, reg, anchors, ann, stages=st, out=bufs,
+                                               from_logits=a.logits)
             for _ in range(10):
                 fn()
             mean, mn = bench.event_times(fn, a.iters)

@@ -62,10 +62,13 @@ def make_annotations(rng, bsz, m, size, c, valid_counts):
     return ann
 
 
-def run_loss(losses, cls, reg, anchors, ann, g_cls=1.0, g_reg=1.0):
+def run_loss(losses, cls, reg, anchors, ann, g_cls=1.0, g_reg=1.0, from_logits=False):
+    """from_logits: ``cls`` holds logits; the reference loss is fed torch.sigmoid(cls), as the
+    classification head does (model.py:177,193), and d_cls is the gradient wrt the logits."""
     tc = torch.from_numpy(cls).clone().requires_grad_(True)
     tr = torch.from_numpy(reg).clone().requires_grad_(True)
-    out = losses.FocalLoss()(tc, tr, torch.from_numpy(anchors), torch.from_numpy(ann))
+    probs = torch.sigmoid(tc) if from_logits else tc
+    out = losses.FocalLoss()(probs, tr, torch.from_numpy(anchors), torch.from_numpy(ann))
     total = g_cls * out["classification_loss"].sum() + g_reg * out["regression_loss"].sum()
     if total.requires_grad:          # a batch of empty images yields constants (losses.py:52-53)
         total.backward()
@@ -213,6 +216,31 @@ def main():
         for k, v in d.items():
             flat[f"{name}.{k}"] = v
     np.savez_compressed(os.path.join(OUT, "focal_loss.npz"), **flat)
+
+    # ---------------- loss on logits (sigmoid folded in) ----------------
+    rng = np.random.default_rng(151)
+    lcases = {}
+    ann = make_annotations(rng, 3, 5, 64, 4, [3, 0, 5])
+    lcases["normal"] = run_loss(losses, rng.normal(-4.595, 2.0, (3, n, 4)).astype(np.float32),
+                                rng.normal(0, 1, (3, n, 4)).astype(np.float32), A, ann, 0.7, 1.3,
+                                from_logits=True)
+    ann = make_annotations(rng, 2, 8, 64, 80, [8, 3])
+    lcases["c80"] = run_loss(losses, rng.normal(-4.595, 2.0, (2, n, 80)).astype(np.float32),
+                             rng.normal(0, 1, (2, n, 4)).astype(np.float32), A, ann,
+                             from_logits=True)
+    # logits around the clamp bounds (sigmoid = 1e-4 at -9.21) and far outside any range
+    x = rng.normal(-4.595, 2.0, (1, n, 4)).astype(np.float32)
+    special = np.array([0.0, -9.21034, 9.21034, -9.3, 9.3, -9.1, 9.1, -20.0, 20.0, -100.0, 100.0,
+                        -1e4, 1e4, 6.9, 8.5, -0.0], np.float32)
+    x.reshape(-1)[: special.size * 40] = np.tile(special, 40)
+    ann = make_annotations(rng, 1, 4, 64, 4, [4])
+    lcases["extreme"] = run_loss(losses, x, rng.normal(0, 1, (1, n, 4)).astype(np.float32), A, ann,
+                                 from_logits=True)
+    flat = {}
+    for name, d in lcases.items():
+        for k, v in d.items():
+            flat[f"{name}.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "focal_loss_logits.npz"), **flat)
 
     # ---------------- decode + clip + score threshold ----------------
     rng = np.random.default_rng(202)
