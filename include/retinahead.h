@@ -217,6 +217,11 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
  *   cand_count device i32 [B] or NULL, overflow device i32 [B] or NULL.
  *   out_cap = max_det if max_det > 0, else min(cand_cap, pre_nms_topk or cand_cap).
  * ------------------------------------------------------------------------- */
+/* out[i] = float32 sigmoid(x[i]), the classification head's output activation
+ * (models/retinanet/model.py:177, 193), bit for bit the probability the logits-in modes of
+ * rh_focal_loss_fwd_bwd and rh_postprocess derive from a logit.  x, out device [count]. */
+int rh_sigmoid_f32(const float* x, float* out, int64_t count, rh_stream_t stream);
+
 typedef struct rh_post_params {
   float height, width;   /* image size used by the clip (utils.py:134) */
   float score_thresh;    /* 0.05 model.py:325 */
@@ -225,6 +230,9 @@ typedef struct rh_post_params {
   int32_t pre_nms_topk;
   int32_t max_det;
   int32_t cand_cap;
+  int32_t from_logits;   /* 1: classifications are the head's logits; scores are their float32
+                            sigmoid (model.py:177, 193) as rh_sigmoid_f32 computes it, and the
+                            result equals the probability-mode result for those probabilities */
 } rh_post_params;
 
 size_t rh_postprocess_workspace_bytes(int32_t batch, int64_t n, int32_t num_classes,

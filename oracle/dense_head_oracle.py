@@ -423,7 +423,7 @@ def nms_bruteforce(boxes, scores, iou_threshold, labels=None):
 # --------------------------------------------------------------------------
 def postprocess_image(classification, regression, anchors, height, width,
                       score_thresh=0.05, iou_thresh=0.5, mode="agnostic",
-                      pre_nms_topk=None, max_det=None, boxes=None):
+                      pre_nms_topk=None, max_det=None, boxes=None, from_logits=False):
     """One image: (scores f32[K'], labels i64[K'], boxes f32[K',4]).
 
     model.py:320-340: decode, clip, per-anchor max over classes, keep
@@ -434,9 +434,12 @@ def postprocess_image(classification, regression, anchors, height, width,
     index) before NMS; ``max_det`` truncates the kept list.  ``boxes`` [N,4], when
     given, replaces the decode + clip step (lets a test feed the device's own decoded
     boxes, whose exp() may differ from numpy's in the last place, so that keep lists
-    can be compared exactly).
+    can be compared exactly).  ``from_logits``: ``classification`` holds logits; the head's
+    sigmoid (model.py:177,193) is applied first.
     """
     p = np.asarray(classification, dtype=F32)
+    if from_logits:
+        p = sigmoid_f32(p)
     if boxes is None:
         boxes = clip_boxes(bbox_transform(np.asarray(anchors, F32).reshape(1, -1, 4),
                                           np.asarray(regression, F32)[None]), height, width)[0]

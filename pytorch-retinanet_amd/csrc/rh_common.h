@@ -78,4 +78,18 @@ __device__ __forceinline__ int wave_sum(int v) {
 __device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
 inline uint32_t div_magic(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
 
+// float32 sigmoid of a head logit (models/retinanet/model.py:177, 193), shared by the loss
+// stream and the score scan so that both see the same probability for the same logit.
+// exp is the hardware exp2 (1 ulp; the rounding of x * log2(e) adds |x| * 4e-8 relative) and
+// the division is the hardware reciprocal plus one Newton step.  The step matters: 1 - p is
+// exact given p, so for p close to 1 the last bit of p decides several digits of a loss
+// gradient, and a plain 1-ulp reciprocal would show there.  exp2 is capped so that 1 + e
+// stays finite for the Newton step.
+__device__ __forceinline__ float sigmoid_f32(const float x) {
+  const float e = fminf(__builtin_amdgcn_exp2f(x * -1.442695040888963f), 1e30f);
+  const float d = 1.0f + e;
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+
 }  // namespace rh

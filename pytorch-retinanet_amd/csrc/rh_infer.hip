@@ -122,10 +122,14 @@ __device__ __forceinline__ void emit_tile(const int tile, const int rows, const 
 // those elements touch the per-row (max, first arg-max) slots, through 64-bit LDS atomic
 // max (order-independent); everything else is one compare per float4: a pure read stream.
 // Host guarantees 4 <= C < 8192, 16-byte aligned classifications.
-template <int U>
+// kLogits: the elements are logits.  A cheap test against `pre` (a logit safely below the one
+// whose sigmoid equals the threshold) filters the stream; only elements that pass it are
+// turned into probabilities, and everything after works on those, so arg-max ties and the
+// threshold test are decided on float32 probabilities exactly as in probability mode.
+template <int U, bool kLogits>
 __global__ __launch_bounds__(kThreads) void score_scan_tile_kernel(
     const float* __restrict__ prob, TileCands tc, int C, int total_rows, unsigned magic_c,
-    float thresh) {
+    float thresh, float pre) {
   __shared__ u64 s_best[kTileRows];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void score_scan_tile_kernel(
       const int v = v0 + u * kThreads;
       if (v < nvec) {
         const float m = fmaxf(fmaxf(val[u].x, val[u].y), fmaxf(val[u].z, val[u].w));
-        if (m > thresh) {
+        if (m > (kLogits ? pre : thresh)) {
           const unsigned x = (unsigned)v << 2;
           int r = (int)fast_div(x, magic_c);
           int col = (int)x - r * C;
@@ -160,7 +164,14 @@ __global__ __launch_bounds__(kThreads) void score_scan_tile_kernel(
               col -= C;
               r += 1;
             }
-            if (in[e] > thresh) atomicMax(&s_best[r], make_key(in[e], (unsigned)col));
+            if (kLogits) {
+              if (in[e] > pre) {
+                const float pv = sigmoid_f32(in[e]);
+                if (pv > thresh) atomicMax(&s_best[r], make_key(pv, (unsigned)col));
+              }
+            } else if (in[e] > thresh) {
+              atomicMax(&s_best[r], make_key(in[e], (unsigned)col));
+            }
             col += 1;
           }
         }
@@ -171,7 +182,8 @@ __global__ __launch_bounds__(kThreads) void score_scan_tile_kernel(
     const int x = (nvec << 2) + tid;   // < 4 trailing elements of the last tile
     if (x < elems) {
       const int r = x / C, col = x - r * C;
-      const float pv = prob[base + x];
+      const float xv = prob[base + x];
+      const float pv = kLogits ? (xv > pre ? sigmoid_f32(xv) : 0.0f) : xv;
       if (pv > thresh) atomicMax(&s_best[r], make_key(pv, (unsigned)col));
     }
   }
@@ -180,6 +192,7 @@ __global__ __launch_bounds__(kThreads) void score_scan_tile_kernel(
 }
 
 // Generic kernel: any C and alignment; each wave reduces 16 of the tile's rows, scalar loads.
+template <bool kLogits>
 __global__ __launch_bounds__(kThreads) void score_scan_rows_kernel(const float* __restrict__ prob,
                                                                    TileCands tc, int C,
                                                                    int total_rows, float thresh) {
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void score_scan_rows_kernel(const float* 
     if (r < rows) {
       const float* p = prob + (size_t)(row0 + r) * C;
       for (int c = lane; c < C; c += 64) {
-        const u64 k = make_key(p[c], (unsigned)c);
+        const u64 k = make_key(kLogits ? sigmoid_f32(p[c]) : p[c], (unsigned)c);
         best = k > best ? k : best;
       }
     }
@@ -206,6 +219,14 @@ __global__ __launch_bounds__(kThreads) void score_scan_rows_kernel(const float* 
   }
   __syncthreads();
   if (threadIdx.x < kTileRows) emit_tile(tile, rows, row0, s_best, thresh, tc);
+}
+
+// out = sigmoid_f32(x): the probabilities the logits-in modes work with.
+__global__ __launch_bounds__(kThreads) void sigmoid_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ out, long long count) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += stride)
+    out[i] = sigmoid_f32(x[i]);
 }
 
 // Keys for a plain (boxes, scores) NMS call: every box is a candidate.
@@ -1169,6 +1190,18 @@ int rh_bbox_transform_f32(const float* boxes, const float* deltas, int32_t batch
   return RH_OK;
 }
 
+int rh_sigmoid_f32(const float* x, float* out, int64_t count, rh_stream_t stream) {
+  RH_REQUIRE(count >= 0, RH_ESHAPE, "count < 0");
+  if (count == 0) return RH_OK;
+  RH_REQUIRE(x && out, RH_EINVAL, "null pointer");
+  long long blocks = (count + kThreads - 1) / kThreads;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream,
+                     x, out, (long long)count);
+  RH_CHECK_LAUNCH("sigmoid_kernel");
+  return RH_OK;
+}
+
 int rh_clip_boxes_f32(float* boxes, int64_t rows, float width, float height, rh_stream_t stream) {
   RH_REQUIRE(rows >= 0, RH_ESHAPE, "rows < 0");
   if (rows == 0) return RH_OK;
@@ -1221,6 +1254,15 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
   return launch_nms(p, w, iou_threshold, labels != nullptr, out, s);
 }
 
+// A logit whose sigmoid is certainly below `thresh` in float32 (and -inf / +inf when every /
+// no probability can exceed the threshold): elements at or below it need no sigmoid.
+static float logit_prefilter(float thresh) {
+  if (!(thresh > 0.0f)) return -INFINITY;
+  if (thresh >= 1.0f) return INFINITY;
+  const double t = (double)thresh;
+  return (float)(log(t / (1.0 - t)) - 1e-3);
+}
+
 static int check_post(int32_t batch, int64_t n, int32_t c, const rh_post_params* q) {
   RH_REQUIRE(q, RH_EINVAL, "null params");
   RH_REQUIRE(batch >= 1 && n >= 1 && c >= 1, RH_ESHAPE, "bad shape batch=%d n=%lld classes=%d", batch,
@@ -1268,14 +1310,17 @@ int rh_postprocess(const float* classifications, const float* regressions, const
     const bool tile = num_classes >= 4 && num_classes < 8192 && aligned16(classifications);
     if (tile) {
       const bool u5 = ((kTileRows * num_classes / 4 + kThreads - 1) / kThreads) % 5 == 0;
-      auto kern = u5 ? score_scan_tile_kernel<5> : score_scan_tile_kernel<4>;
+      auto kern = q->from_logits
+                      ? (u5 ? score_scan_tile_kernel<5, true> : score_scan_tile_kernel<4, true>)
+                      : (u5 ? score_scan_tile_kernel<5, false> : score_scan_tile_kernel<4, false>);
       hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications, tc,
                          num_classes, total_rows, div_magic((unsigned)num_classes),
-                         q->score_thresh);
+                         q->score_thresh, logit_prefilter(q->score_thresh));
       RH_CHECK_LAUNCH("score_scan_tile_kernel");
     } else {
-      hipLaunchKernelGGL(score_scan_rows_kernel, dim3(num_tiles), dim3(kThreads), 0, s,
-                         classifications, tc, num_classes, total_rows, q->score_thresh);
+      auto kern = q->from_logits ? score_scan_rows_kernel<true> : score_scan_rows_kernel<false>;
+      hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications, tc,
+                         num_classes, total_rows, q->score_thresh);
       RH_CHECK_LAUNCH("score_scan_rows_kernel");
     }
   }

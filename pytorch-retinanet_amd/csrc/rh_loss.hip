@@ -311,22 +311,11 @@ __device__ __forceinline__ float focal_any(const float p, const bool one, const 
 }
 
 // Logits-in mode: the head's nn.Sigmoid (model.py:177, 193) is folded into the stream.  The
-// element is a logit x; p = 1 / (1 + exp(-x)) in float32, the loss is the probability-mode
-// loss of p and the gradient flows through the sigmoid as autograd does it:
-// dL/dx = dL/dp * p * (1 - p).
+// element is a logit x; p = sigmoid_f32(x), the loss is the probability-mode loss of p and
+// the gradient flows through the sigmoid as autograd does it: dL/dx = dL/dp * p * (1 - p).
 // The stream has room for about a dozen more vector instructions per element before it
-// stops being bound by HBM, so exp is the hardware exp2 (1 ulp; the rounding of x * log2(e)
-// adds |x| * 4e-8 relative, far inside the 1e-5 bar) and the division is the hardware
-// reciprocal plus one Newton step.  The step matters: 1 - p is exact given p, so for p close
-// to 1 the last bit of p decides several digits of the gradient, and a plain 1-ulp reciprocal
-// would show there.  exp2 is capped so that 1 + e stays finite for the Newton step.
-__device__ __forceinline__ float sigmoid_f32(const float x) {
-  const float e = fminf(__builtin_amdgcn_exp2f(x * -1.442695040888963f), 1e30f);
-  const float d = 1.0f + e;
-  const float r = __builtin_amdgcn_rcpf(d);
-  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-}
-
+// stops being bound by HBM, which is what the hardware exp2 / reciprocal form of sigmoid_f32
+// costs; an expf call and an IEEE division took the kernel from 122 to 164 us.
 template <bool kLogits>
 __device__ __forceinline__ float focal_zero_in(const float x, const FocalConst k, const float k0l,
                                                const float k0g, float& grad) {

@@ -55,6 +55,7 @@ class PostParams(C.Structure):
         ("pre_nms_topk", C.c_int32),
         ("max_det", C.c_int32),
         ("cand_cap", C.c_int32),
+        ("from_logits", C.c_int32),
     ]
 
 
@@ -80,6 +81,7 @@ SIGNATURES = {
     "rh_generic_focal_fwd_bwd": (C.c_int, [_P, _P, _I64, _F, _F, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
     "rh_bbox_transform_f32": (C.c_int, [_P, _P, _I32, _I64, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "rh_clip_boxes_f32": (C.c_int, [_P, _I64, _F, _F, _P]),
+    "rh_sigmoid_f32": (C.c_int, [_P, _P, _I64, _P]),
     "rh_nms_workspace_bytes": (_SZ, [_I64]),
     "rh_nms": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
     "rh_postprocess_workspace_bytes": (_SZ, [_I32, _I64, _I32, C.POINTER(PostParams)]),

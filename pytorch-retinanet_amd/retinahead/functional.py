@@ -290,6 +290,18 @@ def bbox_transform(boxes, deltas, mean=None, std=None):
     return out
 
 
+def sigmoid(logits):
+    """float32 sigmoid as the logits-in modes of the loss and of post-processing compute it (the
+    head's output activation, models/retinanet/model.py:177,193)."""
+    dev = _dev_check(logits)
+    x = _f32c(logits)
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_sigmoid_f32(_p(x), _p(out), x.numel(), _stream(dev)),
+                   "rh_sigmoid_f32")
+    return out
+
+
 def clip_boxes_(boxes, height, width):
     """In place (utils.py:136-140)."""
     dev = _dev_check(boxes)
@@ -334,7 +346,7 @@ def nms(boxes, scores, iou_threshold, labels: Optional[torch.Tensor] = None):
 
 def postprocess_raw(classifications, regressions, anchors_t, height, width, score_thresh=0.05,
                     iou_thresh=0.5, per_class=False, pre_nms_topk=0, max_det=0, cand_cap=4096,
-                    stages=_lib.POST_ALL, out=None):
+                    stages=_lib.POST_ALL, out=None, from_logits=False):
     """One pass of the batched post-processing kernels; no host synchronisation.
 
     Returns dict(scores [B,cap], labels [B,cap] i64, boxes [B,cap,4], counts [3,B] i32) where
@@ -353,7 +365,7 @@ def postprocess_raw(classifications, regressions, anchors_t, height, width, scor
     box_cap = min(cand_cap, topk) if topk > 0 else cand_cap
     out_cap = max_det if max_det > 0 else box_cap
     params = _lib.PostParams(float(height), float(width), float(score_thresh), float(iou_thresh),
-                             int(bool(per_class)), topk, max_det, cand_cap)
+                             int(bool(per_class)), topk, max_det, cand_cap, int(bool(from_logits)))
     lib = _lib.load()
     if out is None:
         out = dict(

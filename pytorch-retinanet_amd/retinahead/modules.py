@@ -219,7 +219,7 @@ def batched_nms(boxes, scores, labels, iou_threshold):
 
 def postprocess(classification, regression, anchors, img_batch, score_thresh=0.05, iou_thresh=0.5,
                 mode="agnostic", pre_nms_topk=None, max_det=None, max_candidates=4096,
-                output="dicts"):
+                output="dicts", from_logits=False):
     """Inference post-processing for the whole batch; replaces models/retinanet/model.py:320-340.
 
     classification [B,N,C] probabilities, regression [B,N,4], anchors [1,N,4]; ``img_batch`` is the
@@ -230,7 +230,9 @@ def postprocess(classification, regression, anchors, img_batch, score_thresh=0.0
     visualize.py:95-101 reads) or image 0's ``[scores, labels, boxes]`` (``output='tuple'``, the
     form of model.py:340).  ``max_candidates`` sizes the first attempt's buffers; if an image has
     more candidates over the threshold the call is repeated with room for all of them, so results
-    never depend on it.
+    never depend on it.  ``from_logits``: ``classification`` holds the head's logits (the
+    ``nn.Sigmoid`` of model.py:177,193 left out); scores are their float32 sigmoid and the result
+    is the one the probability form gives for ``retinahead.sigmoid(classification)``.
     """
     if mode not in ("agnostic", "per_class"):
         raise ValueError("mode must be 'agnostic' or 'per_class'")
@@ -242,7 +244,8 @@ def postprocess(classification, regression, anchors, img_batch, score_thresh=0.0
     cap = min(n, int(max_candidates))
     while True:
         out = F.postprocess_raw(classification, regression, anchors, height, width, score_thresh,
-                                iou_thresh, mode == "per_class", pre_nms_topk or 0, max_det or 0, cap)
+                                iou_thresh, mode == "per_class", pre_nms_topk or 0, max_det or 0, cap,
+                                from_logits=from_logits)
         counts = out["counts"].cpu()          # the one host read: output sizes are data dependent
         if int(counts[2].max()) == 0 or cap >= n:
             break

@@ -348,6 +348,50 @@ def test_postprocess_agnostic(rh):
     assert len(tup) == 3 and torch.equal(tup[0], res[0]["scores"])
 
 
+def test_sigmoid_and_postprocess_on_logits(rh):
+    """The logits-in post-processing equals the probability form applied to the library's own
+    float32 sigmoid, bit for bit; that sigmoid is within a few ulp of numpy's / the oracle's."""
+    rng = np.random.default_rng(31)
+    x = np.concatenate([rng.normal(-4, 3, 5000), [0.0, -0.0, 9.21034, -9.21034, 20, -20, 88, -88,
+                                                    100, -100, 1e4, -1e4, np.inf, -np.inf]]).astype(np.float32)
+    got = rh.sigmoid(dev(x)).cpu().numpy()
+    want = O.sigmoid_f32(x)
+    assert got.dtype == np.float32 and np.isfinite(got).all()
+    assert (got >= 0).all() and (got <= 1).all()
+    # a few ulp from the reciprocal, exp2 and numpy's own exp, plus the rounding of the exp2
+    # argument x * log2(e), which is worth up to |x| ulp; below x = -60 (p < 1e-26) the value
+    # is only required to be tiny (exp2 is capped at 1e30 inside)
+    mid = np.abs(x) <= 60
+    ulp = np.spacing(np.abs(want[mid]))
+    assert (np.abs(got[mid].astype(np.float64) - want[mid]) <= (4 + 2 * np.abs(x[mid])) * ulp).all()
+    assert (got[x < -60] <= 1e-26).all() and (got[x > 60] == 1.0).all()
+
+    size, c, bsz = 160, 20, 3
+    anc = O.anchors_for_image(size, size)
+    n = anc.shape[1]
+    logits = rng.normal(-6.0, 2.2, (bsz, n, c)).astype(np.float32)
+    logits[0, :40, 3] = np.linspace(-3.2, -2.7, 40, dtype=np.float32)     # around logit(0.05) = -2.944
+    logits[1, 10:14, :] = 12.0                                              # saturated ties: first class wins
+    reg = rng.normal(0, 0.4, (bsz, n, 4)).astype(np.float32)
+    xl, rg, an = dev(logits), dev(reg), dev(anc)
+    probs = rh.sigmoid(xl)
+    for mode, topk in (("agnostic", None), ("per_class", 300)):
+        a = rh.postprocess(xl, rg, an, (size, size), mode=mode, pre_nms_topk=topk, from_logits=True)
+        b = rh.postprocess(probs, rg, an, (size, size), mode=mode, pre_nms_topk=topk)
+        for ra, rb in zip(a, b):
+            assert ra["scores"].numel() > 0
+            for k in ("scores", "labels", "boxes"):
+                assert torch.equal(ra[k], rb[k]), (mode, k)
+    # and against the oracle working from the same probabilities
+    boxes = rh.ClipBoxes()(rh.BBoxTransform()(an, rg), torch.zeros(1, 3, size, size, device="cuda"))
+    so, lo, bo = O.postprocess_image(probs[1].cpu().numpy(), reg[1], anc, size, size,
+                                     boxes=boxes[1].cpu().numpy())
+    res = rh.postprocess(xl, rg, an, (size, size), from_logits=True)[1]
+    assert np.array_equal(res["scores"].cpu().numpy(), so)
+    assert np.array_equal(res["labels"].cpu().numpy(), lo)
+    assert np.array_equal(res["boxes"].cpu().numpy(), bo)
+
+
 def test_postprocess_per_class_topk_maxdet(rh):
     cls, reg, anc = infer_batch(2, 2, 192, 13, mu=-4.0)
     check_post(rh, cls, reg, anc, 192, mode="per_class")
