@@ -157,6 +157,30 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                           float* per_image, int32_t* num_pos, int32_t* status, void* workspace,
                           size_t workspace_bytes, int32_t stages, rh_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * The same fused loss, reading the heads' outputs where they lie: per pyramid level l a
+ * classification tensor [B, A*C, H_l, W_l] and a regression tensor [B, A*4, H_l, W_l] (the
+ * convolutions' NCHW outputs), instead of the flat [B,N,C] / [B,N,4] tensors the reference
+ * builds from them by permute + contiguous + view + cat
+ * (models/retinanet/model.py:152-154, 196-202, 311-313).  Anchor n = off_l + (y*W_l + x)*A + a
+ * is channel group a of cell (y, x) of level l; N = A * sum_l H_l*W_l must equal the number of
+ * anchor rows.  Gradients are written in the layout of the inputs.
+ *   cls_levels, reg_levels, d_cls_levels, d_reg_levels: HOST arrays of num_levels device pointers
+ *   heights, widths: HOST arrays [num_levels]; num_levels <= 8
+ * Everything else as rh_focal_loss_fwd_bwd (params->from_logits included).
+ * ------------------------------------------------------------------------- */
+size_t rh_focal_loss_levels_workspace_bytes(int32_t batch, int32_t num_levels, const int32_t* heights,
+                                            const int32_t* widths, int32_t anchors_per_cell,
+                                            int32_t m);
+int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* const* reg_levels,
+                                 const float* anchors, const float* annotations, int32_t batch,
+                                 int32_t num_levels, const int32_t* heights, const int32_t* widths,
+                                 int32_t anchors_per_cell, int32_t num_classes, int32_t m,
+                                 const rh_focal_params* params, float* const* d_cls_levels,
+                                 float* const* d_reg_levels, float* losses, float* per_image,
+                                 int32_t* num_pos, int32_t* status, void* workspace,
+                                 size_t workspace_bytes, int32_t stages, rh_stream_t stream);
+
 /* Applies upstream gradients to the stored gradients without a host read:
  * x *= (*scale_x) / assumed and y *= (*scale_y) / assumed, in place, one launch.  An array whose
  * scale equals `assumed` is not touched (no memory traffic); a NULL scale pointer zeroes the

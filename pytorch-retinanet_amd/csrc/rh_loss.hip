@@ -66,12 +66,24 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 constexpr int kAssignPer = 2;
 constexpr int kAssignBlock = kThreads * kAssignPer;   // anchors per block
 
+// Where the packed codes go.  num_levels == 0: code[j*N + n], the order of the flat [B,N,C]
+// tensors.  Otherwise the head-layout kernel's order: within pyramid level l the codes of
+// anchor a form a plane of H*W cells, code[j*N + off_l + a*hw_l + cell], so that a workgroup
+// that walks the cells of one (level, anchor) reads its codes as one contiguous run.
+constexpr int kMaxLevels = 8;
+struct CodeLayout {
+  int num_levels;
+  int a;                           // anchors per cell
+  int anchor_off[kMaxLevels + 1];  // first anchor of each level, then N
+  int hw[kMaxLevels];
+};
+
 __global__ __launch_bounds__(kThreads) void assign_kernel(
     const float4* __restrict__ anchors, const float* __restrict__ ann, GtRec* __restrict__ gt,
     int* __restrict__ gt_count, int* __restrict__ status, int* __restrict__ code,
     unsigned char* __restrict__ state, int* __restrict__ argmax, int* __restrict__ label,
     float* __restrict__ iou_max, int* __restrict__ blk_pos, int N, int M, int C,
-    float neg_thresh, float pos_thresh) {
+    float neg_thresh, float pos_thresh, CodeLayout lay) {
   __shared__ float4 s_box[kGtChunk];
   __shared__ float s_area[kGtChunk];
   __shared__ int s_lab[kGtChunk];
@@ -202,7 +214,17 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     }
     if (n < N) {
       const size_t o = (size_t)j * N + n;
-      if (code) code[o] = cd;
+      if (code) {
+        size_t oc = o;
+        if (lay.num_levels) {
+          int l = 0;
+          while (l + 1 < lay.num_levels && n >= lay.anchor_off[l + 1]) ++l;
+          const int r = n - lay.anchor_off[l];
+          const int cell = r / lay.a;
+          oc = (size_t)j * N + lay.anchor_off[l] + (size_t)(r - cell * lay.a) * lay.hw[l] + cell;
+        }
+        code[oc] = cd;
+      }
       if (state) state[o] = (unsigned char)st;
       if (argmax) argmax[o] = best_idx[k];
       if (label) label[o] = lb;
@@ -618,6 +640,199 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Head-layout stream kernel.  The heads produce, per pyramid level, a tensor [B, A*C, H, W]
+// (classification) and [B, A*4, H, W] (regression); the reference turns them into the flat
+// [B, N, C] / [B, N, 4] tensors by permute + contiguous + view + cat (model.py:152-154,
+// 196-202, 311-313), one full copy of the N x C data each way.  This kernel reads the level
+// tensors where they lie and writes the gradients in the same layout (what the head
+// convolutions' backward consumes).  Anchor index of (level l, cell s = y*W + x, anchor a):
+// n = off_l + s*A + a; class c of it is channel a*C + c.
+//
+// Work unit u = a*HW + cell of a level ("anchor-cell": the order of the code planes the
+// assignment kernel writes for this layout, so a unit's code is code[off_l + u]).  A
+// workgroup owns 1024 consecutive units of one level of one image (4 per thread) and one
+// share of the C class planes (blockIdx.y; share 0 also does the four regression planes); it
+// walks its planes U at a time, each a contiguous run of cells: float4 per thread when H*W is
+// a multiple of 4 and the tensors are 16-byte aligned (then a thread's four units share their
+// anchor), else one unit per access.  Small levels fill workgroups as well as large ones,
+// which matters: a workgroup lives for a few memory latencies whatever it carries.
+// partials layout: [B][gridDim.x * gridDim.y][2].
+// ---------------------------------------------------------------------------
+constexpr int kLvlThreads = 256;
+constexpr int kLvlChunk = 4 * kLvlThreads;   // units per workgroup: 4 per thread
+
+// Sum over the workgroup (any multiple of 64 threads), fixed order.
+__device__ __forceinline__ float block_sum_any(float v, float* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+  return t;
+}
+
+struct LevelTable {
+  const float* cls[kMaxLevels];
+  float* dcls[kMaxLevels];
+  const float* reg[kMaxLevels];
+  float* dreg[kMaxLevels];
+  int hw[kMaxLevels];            // cells of the level
+  int anchor_off[kMaxLevels];    // index of the level's first anchor
+  int chunk_begin[kMaxLevels + 1];
+  int vec4[kMaxLevels];          // float4 path usable
+  int num_levels;
+};
+
+template <bool kLogits>
+__global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
+    LevelTable lt, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
+    const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
+    float* __restrict__ partials, int N, int A, int C, int M, FocalConst fc, float gcls, float greg,
+    float divisor) {
+  __shared__ float s_red[kLvlThreads / 64];
+  __shared__ int s_tmp[kLvlThreads / 64];
+  const int tid = threadIdx.x;
+  const int part = blockIdx.y, csplit = gridDim.y, j = blockIdx.z;
+  const int cper = (C + csplit - 1) / csplit;
+  const int c_lo = part * cper, c_hi = min(C, c_lo + cper);
+  int l = 0;
+  while (l + 1 < lt.num_levels && (int)blockIdx.x >= lt.chunk_begin[l + 1]) ++l;
+  const int hw = lt.hw[l];
+  const int units = A * hw;
+  const int s0 = ((int)blockIdx.x - lt.chunk_begin[l]) * kLvlChunk;
+  const bool v4 = lt.vec4[l] != 0;
+  const int np = sum_blk_pos(blk_pos, nblk, j, s_tmp);
+  const float sc = gcls / ((float)max(np, 1) * divisor);
+  const float rsc = greg / ((4.0f * (float)np) * divisor);
+
+  // my four units: consecutive (float4 path) or strided by the block size (scalar path)
+  const int* cplane = code + (size_t)j * N + lt.anchor_off[l];
+  int cd[4], cell[4], base_c[4], base_r[4];
+  bool ok[4];
+  bool special = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int u = v4 ? s0 + tid * 4 + k : s0 + tid + k * kLvlThreads;
+    ok[k] = u < units;                         // a dead unit loads and stores nothing
+    const int uc = min(u, units - 1);
+    cd[k] = ok[k] ? cplane[uc] : kCodeNeg;
+    const int a = uc / hw;
+    cell[k] = uc - a * hw;
+    // offsets of the unit inside image j's [A*C, HW] / [A*4, HW] blocks, class / coordinate 0
+    base_c[k] = a * C * hw + cell[k];
+    base_r[k] = a * 4 * hw + cell[k];
+    special |= cd[k] != kCodeNeg;
+  }
+  // decide per wave, not per lane: a wave with a single positive or ignored unit would
+  // otherwise run both element paths one after the other
+  special = __ballot(special) != 0ull;
+  float cl = 0.f, rl = 0.f;
+
+  // ---- regression planes
+  if (part == 0) {
+    const float* rp = lt.reg[l] + (size_t)j * A * 4 * hw;
+    float* dp = lt.dreg[l] + (size_t)j * A * 4 * hw;
+    float g[4][4];   // [coordinate][unit]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q][k] = 0.f;
+      if (cd[k] >= 0) {
+        const int a = base_r[k] / (4 * hw);
+        const float4 an = anchors[lt.anchor_off[l] + cell[k] * A + a];
+        const GtRec r = gt[(size_t)j * M + (cd[k] >> 16)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float gr;
+          rl += smooth_l1_coord(q, an, r, rp[(size_t)base_r[k] + (size_t)q * hw], &gr);
+          g[q][k] = gr * rsc;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (v4) {
+        if (ok[0]) {
+          v4f o;
+          o.x = g[q][0]; o.y = g[q][1]; o.z = g[q][2]; o.w = g[q][3];
+          __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dp + (size_t)base_r[0] + (size_t)q * hw));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ok[k]) dp[(size_t)base_r[k] + (size_t)q * hw] = g[q][k];
+      }
+    }
+  }
+
+  // ---- classification planes c_lo .. c_hi-1 of every unit
+  const float* cp = lt.cls[l] + (size_t)j * A * C * hw;
+  float* dcp = lt.dcls[l] + (size_t)j * A * C * hw;
+  const float k0l = -(1.0f - fc.alpha) * kLn2, k0g = -(1.0f - fc.alpha) * sc;
+  constexpr int U = 4;
+  for (int c0 = c_lo; c0 < c_hi; c0 += U) {
+    float in[U][4];
+    // loads first, all unconditional (class and unit indices clamped)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t co = (size_t)min(c0 + u, C - 1) * hw;
+      if (v4) {
+        const v4f val = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cp + base_c[0] + co));
+        in[u][0] = val.x; in[u][1] = val.y; in[u][2] = val.z; in[u][3] = val.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in[u][k] = cp[base_c[k] + co];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u;
+      if (c < c_hi) {
+        float out[4];
+        if (!special) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float lk = focal_zero_in<kLogits>(in[u][k], fc, k0l, k0g, out[k]);
+            cl += ok[k] ? lk : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool one = cd[k] >= 0 && (cd[k] & 0xFFFF) == c;
+            const bool live = cd[k] != kCodeIgn && ok[k];
+            float gk;
+            const float lk = focal_any_in<kLogits>(in[u][k], one, fc, sc, gk);
+            out[k] = live ? gk : 0.f;
+            cl += live ? lk : 0.f;
+          }
+        }
+        const size_t co = (size_t)c * hw;
+        if (v4) {
+          if (ok[0]) {
+            v4f o;
+            o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dcp + base_c[0] + co));
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (ok[k]) dcp[base_c[k] + co] = out[k];
+        }
+      }
+    }
+  }
+  const float t0 = block_sum_any(cl, s_red);
+  const float t1 = block_sum_any(rl, s_red);
+  if (tid == 0) {
+    const size_t nb = (size_t)gridDim.x * gridDim.y;
+    float* o = partials + ((size_t)j * nb + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    o[0] = t0;
+    o[1] = t1;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Final reduction, one workgroup of 16 waves, fixed order, double accumulation.
 // Wave w sums the partials of images w, w+16, ... (lane-strided, then a butterfly)
 // and applies the normalisers of losses.py:94 and :134; wave 0 then forms the batch
@@ -764,13 +979,67 @@ static int check_assign_shapes(int batch, long long n, int m, int c) {
 static int launch_assign(const float* anchors, const float* annotations, int batch, long long n,
                          int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                          unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
-                         hipStream_t s) {
+                         hipStream_t s, const CodeLayout& lay = CodeLayout{}) {
   dim3 grid((unsigned)w.nblk, (unsigned)batch);
   hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
                      reinterpret_cast<const float4*>(anchors), annotations, w.gt, w.gt_count, status,
-                     code, state, argmax, label, iou_max, w.blk_pos, (int)n, m, c, neg_t, pos_t);
+                     code, state, argmax, label, iou_max, w.blk_pos, (int)n, m, c, neg_t, pos_t, lay);
   RH_CHECK_LAUNCH("assign_kernel");
   return RH_OK;
+}
+
+
+// ---- head-layout entry points ---------------------------------------------------------------
+struct LevelPlan {
+  long long n;        // anchors per image: A * sum of cells
+  int chunks;         // workgroups along x
+  int chunk_begin[kMaxLevels + 1];
+  int anchor_off[kMaxLevels];
+  int hw[kMaxLevels];
+};
+
+static int make_level_plan(int num_levels, const int32_t* heights, const int32_t* widths, int a,
+                           LevelPlan* p) {  // chunks: workgroups of kLvlChunk anchor-cells
+  RH_REQUIRE(num_levels >= 1 && num_levels <= kMaxLevels, RH_ESHAPE, "num_levels=%d not in [1, %d]",
+             num_levels, kMaxLevels);
+  RH_REQUIRE(heights && widths, RH_EINVAL, "null level shapes");
+  RH_REQUIRE(a >= 1 && a <= 65535, RH_ESHAPE, "anchors_per_cell=%d out of range", a);
+  long long cells = 0;
+  int chunks = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    RH_REQUIRE(heights[l] >= 1 && widths[l] >= 1, RH_ESHAPE, "level %d has shape %d x %d", l,
+               heights[l], widths[l]);
+    const long long hw = (long long)heights[l] * widths[l];
+    RH_REQUIRE(hw < (1ll << 31) && (cells + hw) * a < (1ll << 31), RH_ESHAPE, "levels too large");
+    p->hw[l] = (int)hw;
+    p->anchor_off[l] = (int)(cells * a);
+    p->chunk_begin[l] = chunks;
+    chunks += (int)((hw * a + kLvlChunk - 1) / kLvlChunk);
+    cells += hw;
+  }
+  p->chunk_begin[num_levels] = chunks;
+  p->chunks = chunks;
+  p->n = cells * a;
+  return RH_OK;
+}
+
+// Workgroups that share the class planes of one (image, anchor, chunk): about 16 planes each.
+static int level_csplit(int c) {
+  int s = c / 16;
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+static LossWorkspace carve_levels(void* ws, int batch, long long n, int m, long long blocks) {
+  Carver cv(ws);
+  LossWorkspace w;
+  w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
+  w.gt_count = cv.take<int>(batch);
+  w.nblk = (int)((n + kAssignBlock - 1) / kAssignBlock);
+  w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
+  w.code = cv.take<int>((size_t)batch * n);
+  w.partials = cv.take<float>((size_t)batch * blocks * 2);
+  w.bytes = cv.off;
+  return w;
 }
 
 }  // namespace rh
@@ -901,6 +1170,95 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
                        w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n, tile ? 1 : 0,
                        kGenericBlocks, divisor);
+    RH_CHECK_LAUNCH("finalize_kernel");
+  }
+  return RH_OK;
+}
+
+size_t rh_focal_loss_levels_workspace_bytes(int32_t batch, int32_t num_levels, const int32_t* heights,
+                                            const int32_t* widths, int32_t anchors_per_cell,
+                                            int32_t m) {
+  LevelPlan lp;
+  if (batch < 1 || m < 0 || make_level_plan(num_levels, heights, widths, anchors_per_cell, &lp))
+    return 0;
+  // sized for the largest split so that the query does not depend on the class count
+  return carve_levels(nullptr, batch, lp.n, m, (long long)lp.chunks * 16).bytes;
+}
+
+int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* const* reg_levels,
+                                 const float* anchors, const float* annotations, int32_t batch,
+                                 int32_t num_levels, const int32_t* heights, const int32_t* widths,
+                                 int32_t anchors_per_cell, int32_t num_classes, int32_t m,
+                                 const rh_focal_params* params, float* const* d_cls_levels,
+                                 float* const* d_reg_levels, float* losses, float* per_image,
+                                 int32_t* num_pos, int32_t* status, void* workspace,
+                                 size_t workspace_bytes, int32_t stages, rh_stream_t stream) {
+  LevelPlan lp;
+  if (int e = make_level_plan(num_levels, heights, widths, anchors_per_cell, &lp)) return e;
+  if (int e = check_assign_shapes(batch, lp.n, m, num_classes)) return e;
+  RH_REQUIRE(cls_levels && reg_levels && d_cls_levels && d_reg_levels && anchors &&
+                 (annotations || m == 0) && losses && params,
+             RH_EINVAL, "null pointer");
+  RH_REQUIRE(aligned16(anchors), RH_EALIGN, "anchors must be 16-byte aligned");
+  const int csplit = level_csplit(num_classes);
+  const long long blocks = (long long)lp.chunks * csplit;
+  const size_t need = carve_levels(nullptr, batch, lp.n, m,
+                                   (long long)lp.chunks * 16).bytes;
+  RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
+             "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
+  RH_REQUIRE(params->batch_divisor >= 0, RH_EINVAL, "batch_divisor < 0");
+  RH_REQUIRE((stages & ~RH_STAGE_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
+  RH_REQUIRE(blocks < (1ll << 24), RH_ESHAPE, "too many workgroups per image");
+
+  LevelTable lt{};
+  lt.num_levels = num_levels;
+  for (int l = 0; l < num_levels; ++l) {
+    RH_REQUIRE(cls_levels[l] && reg_levels[l] && d_cls_levels[l] && d_reg_levels[l], RH_EINVAL,
+               "null pointer for level %d", l);
+    lt.cls[l] = cls_levels[l];
+    lt.dcls[l] = d_cls_levels[l];
+    lt.reg[l] = reg_levels[l];
+    lt.dreg[l] = d_reg_levels[l];
+    lt.hw[l] = lp.hw[l];
+    lt.anchor_off[l] = lp.anchor_off[l];
+    lt.chunk_begin[l] = lp.chunk_begin[l];
+    lt.vec4[l] = lp.hw[l] % 4 == 0 && aligned16(cls_levels[l]) && aligned16(d_cls_levels[l]) &&
+                 aligned16(reg_levels[l]) && aligned16(d_reg_levels[l]);
+  }
+  lt.chunk_begin[num_levels] = lp.chunks;
+
+  hipStream_t s = (hipStream_t)stream;
+  const LossWorkspace w = carve_levels(workspace, batch, lp.n, m,
+                                       (long long)lp.chunks * 16);
+  const float divisor = (float)(params->batch_divisor > 0 ? params->batch_divisor : batch);
+  const FocalConst fc{params->alpha, 1e-4f, (float)(1.0 - 1e-4)};
+  if (stages & RH_STAGE_ASSIGN) {
+    CodeLayout lay{};
+    lay.num_levels = num_levels;
+    lay.a = anchors_per_cell;
+    for (int l = 0; l < num_levels; ++l) {
+      lay.anchor_off[l] = lp.anchor_off[l];
+      lay.hw[l] = lp.hw[l];
+    }
+    lay.anchor_off[num_levels] = (int)lp.n;
+    if (int e = launch_assign(anchors, annotations, batch, lp.n, m, num_classes, params->neg_thresh,
+                              params->pos_thresh, w, w.code, nullptr, nullptr, nullptr, nullptr,
+                              status, s, lay))
+      return e;
+  }
+  if (stages & RH_STAGE_STREAM) {
+    auto kern = params->from_logits ? focal_levels_kernel<true> : focal_levels_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(lp.chunks, csplit, batch), dim3(kLvlThreads), 0, s, lt,
+                       reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
+                       w.partials, (int)lp.n, anchors_per_cell, num_classes, m, fc,
+                       params->grad_cls, params->grad_reg, divisor);
+    RH_CHECK_LAUNCH("focal_levels_kernel");
+  }
+  if (stages & RH_STAGE_FINALIZE) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
+                       w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)lp.n, 0,
+                       (int)blocks, divisor);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;

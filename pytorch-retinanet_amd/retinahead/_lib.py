@@ -74,6 +74,10 @@ SIGNATURES = {
     "rh_assign": (C.c_int, [_P, _P, _I32, _I64, _I32, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rh_focal_params_default": (None, [C.POINTER(FocalParams)]),
     "rh_focal_loss_workspace_bytes": (_SZ, [_I32, _I64, _I32, _I32]),
+    "rh_focal_loss_levels_workspace_bytes": (_SZ, [_I32, _I32, _P, _P, _I32, _I32]),
+    "rh_focal_loss_levels_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _I32, _I32,
+                                               C.POINTER(FocalParams), _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                               _I32, _P]),
     "rh_focal_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I32, _I32, C.POINTER(FocalParams),
                                         _P, _P, _P, _P, _P, _P, _P, _SZ, _I32, _P]),
     "rh_apply_upstream_f32": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _F, _P]),

@@ -238,6 +238,79 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     return out
 
 
+def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, alpha=0.25,
+                              neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
+                              batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False):
+    """The fused loss on the heads' own outputs: ``cls_levels[l]`` is [B, A*C, H_l, W_l] and
+    ``reg_levels[l]`` is [B, A*4, H_l, W_l], the tensors the reference permutes, reshapes and
+    concatenates into [B,N,C] / [B,N,4] (models/retinanet/model.py:152-154,196-202,311-313).
+    Returns the dict of :func:`focal_loss_fwd_bwd` with ``d_cls_levels`` / ``d_reg_levels`` (lists,
+    layouts of the inputs; views of the flat buffers ``d_cls_all`` / ``d_reg_all``) instead of
+    the flat gradients."""
+    if len(cls_levels) != len(reg_levels) or not cls_levels:
+        raise RetinaHeadError("need as many classification as regression levels (at least one)")
+    dev = _dev_check(*cls_levels, *reg_levels, anchors_t, annotations)
+    cls = [_f32c(t) for t in cls_levels]
+    reg = [_f32c(t) for t in reg_levels]
+    anc, ann = _anchors2d(anchors_t), _f32c(annotations)
+    bsz = cls[0].shape[0]
+    if any(t.dim() != 4 or t.shape[0] != bsz for t in cls + reg):
+        raise RetinaHeadError("level tensors must be [B, channels, H, W]")
+    hs = [int(t.shape[2]) for t in cls]
+    wsz = [int(t.shape[3]) for t in cls]
+    cells = sum(h * w for h, w in zip(hs, wsz))
+    if anc.shape[0] % cells:
+        raise RetinaHeadError(f"{anc.shape[0]} anchors do not divide over {cells} cells")
+    a = anc.shape[0] // cells
+    if cls[0].shape[1] % a:
+        raise RetinaHeadError(f"{cls[0].shape[1]} classification channels with {a} anchors per cell")
+    c = cls[0].shape[1] // a
+    for tc, tr, h, w in zip(cls, reg, hs, wsz):
+        if tuple(tc.shape) != (bsz, a * c, h, w) or tuple(tr.shape) != (bsz, a * 4, h, w):
+            raise RetinaHeadError("inconsistent level shapes")
+    if ann.dim() != 3 or ann.shape[2] != 5 or ann.shape[0] != bsz:
+        raise RetinaHeadError("annotations must be [B,M,5]")
+    m = ann.shape[1]
+    nl = len(cls)
+    lib = _lib.load()
+    if out is None:
+        small = torch.empty((2 + 4 * bsz,), dtype=torch.float32, device=dev)
+        d_cls_all = torch.empty((sum(t.numel() for t in cls),), dtype=torch.float32, device=dev)
+        d_reg_all = torch.empty((sum(t.numel() for t in reg),), dtype=torch.float32, device=dev)
+
+        def views(flat, like):
+            res, at = [], 0
+            for t in like:
+                res.append(flat[at:at + t.numel()].view(t.shape))
+                at += t.numel()
+            return res
+        out = dict(
+            losses=small[0:2],
+            per_image=small[2:2 + 2 * bsz].view(2, bsz),
+            num_pos=small[2 + 2 * bsz:2 + 3 * bsz].view(torch.int32),
+            status=small[2 + 3 * bsz:].view(torch.int32),
+            d_cls_all=d_cls_all, d_reg_all=d_reg_all,
+            d_cls_levels=views(d_cls_all, cls), d_reg_levels=views(d_reg_all, reg),
+        )
+    params = _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
+                              float(grad_reg), int(batch_divisor), int(bool(from_logits)))
+    ptrs = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    ints = lambda vs: (C.c_int32 * nl)(*vs)
+    h_arr, w_arr = ints(hs), ints(wsz)
+    need = lib.rh_focal_loss_levels_workspace_bytes(bsz, nl, h_arr, w_arr, a, m)
+    if need == 0:
+        raise RetinaHeadError("focal_loss_levels: " + _lib.last_error())
+    with _on_device(dev) as stream:
+        ws = workspace(dev, need, "focal_levels", stream)
+        _lib.check(lib.rh_focal_loss_levels_fwd_bwd(
+            ptrs(cls), ptrs(reg), anc.data_ptr(), ann.data_ptr(), bsz, nl, h_arr, w_arr, a, c, m,
+            C.byref(params), ptrs(out["d_cls_levels"]), ptrs(out["d_reg_levels"]),
+            out["losses"].data_ptr(), out["per_image"].data_ptr(), out["num_pos"].data_ptr(),
+            out["status"].data_ptr(), ws.data_ptr(), ws.numel(), int(stages), stream),
+            "rh_focal_loss_levels_fwd_bwd")
+    return out
+
+
 def apply_upstream(d_cls, g_cls, d_reg, g_reg, assumed=1.0):
     """In place and without a host read: d_cls *= g_cls/assumed, d_reg *= g_reg/assumed (one
     launch; an array whose scale equals ``assumed`` is not touched).  A ``None`` gradient zeroes

@@ -56,6 +56,38 @@ class _DenseHeadLossFn(torch.autograd.Function):
         return out_cls, out_reg, None, None, None
 
 
+class _DenseHeadLevelsLossFn(torch.autograd.Function):
+    """As _DenseHeadLossFn, for per-level head outputs [B, A*C, H, W] / [B, A*4, H, W]."""
+
+    @staticmethod
+    def forward(ctx, cfg, anchors, annotations, num_levels, *levels):
+        cls_levels, reg_levels = levels[:num_levels], levels[num_levels:]
+        out = F.focal_loss_levels_fwd_bwd(
+            cls_levels, reg_levels, anchors, annotations, alpha=cfg["alpha"],
+            neg_thresh=cfg["neg_thresh"], pos_thresh=cfg["pos_thresh"],
+            grad_cls=cfg["expected_grad"], grad_reg=cfg["expected_grad"],
+            batch_divisor=cfg["batch_divisor"], from_logits=cfg["from_logits"])
+        ctx.flat = (out["d_cls_all"], out["d_reg_all"])
+        ctx.grads = (out["d_cls_levels"], out["d_reg_levels"])
+        ctx.expected = cfg["expected_grad"]
+        ctx.in_dtypes = [t.dtype for t in levels]
+        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
+        losses = out["losses"]
+        return losses[0:1], losses[1:2]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        if ctx.flat is None:
+            raise RetinaHeadError("the fused loss keeps one set of gradients: backward() can run "
+                                  "once per forward()")
+        (d_cls_all, d_reg_all), (d_cls, d_reg) = ctx.flat, ctx.grads
+        ctx.flat = ctx.grads = None
+        F.apply_upstream(d_cls_all, g_cls, d_reg_all, g_reg, ctx.expected)
+        grads = [g.to(dt) for g, dt in zip(list(d_cls) + list(d_reg), ctx.in_dtypes)]
+        need = ctx.needs_input_grad[4:]
+        return (None, None, None, None) + tuple(g if n else None for g, n in zip(grads, need))
+
+
 class FocalLoss(nn.Module):
     """Replaces FocalLoss (models/retinanet/losses.py:26-141).
 
@@ -98,6 +130,19 @@ class FocalLoss(nn.Module):
     def forward(self, classifications, regressions, anchors, annotations):
         cls_loss, reg_loss = _DenseHeadLossFn.apply(classifications, regressions, anchors,
                                                     annotations, self.cfg)
+        if self.check_labels:
+            if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
+                raise IndexError("annotation label outside [0, num_classes)")
+        return {"classification_loss": cls_loss, "regression_loss": reg_loss}
+
+    def forward_levels(self, cls_levels, reg_levels, anchors, annotations):
+        """The same loss on the heads' per-level outputs, without the permute / view / cat of
+        models/retinanet/model.py:152-154,196-202,311-313: ``cls_levels[l]`` is the classification
+        convolution's output [B, A*C, H_l, W_l] (probabilities, or logits with ``from_logits``),
+        ``reg_levels[l]`` the regression convolution's [B, A*4, H_l, W_l], levels in the order of
+        the anchors.  Gradients arrive in the same layouts."""
+        cls_loss, reg_loss = _DenseHeadLevelsLossFn.apply(self.cfg, anchors, annotations,
+                                                          len(cls_levels), *cls_levels, *reg_levels)
         if self.check_labels:
             if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
                 raise IndexError("annotation label outside [0, num_classes)")

@@ -182,6 +182,66 @@ def test_loss_on_logits_vs_oracle_and_probability_mode(rh, bsz, size, c, m, vali
     assert torch.equal(out["d_regressions"], prob["d_regressions"])
 
 
+def flat_from_levels(levels, a, last):
+    """[B, A*last, H, W] per level -> [B, N, last] as the reference builds it:
+    permute(0, 2, 3, 1), view(B, -1, last), cat over levels (model.py:152-154,196-202,311-313)."""
+    parts = [t.transpose(0, 2, 3, 1).reshape(t.shape[0], -1, last) for t in levels]
+    return np.concatenate(parts, axis=1)
+
+
+def levels_from_flat(flat, shapes, a, last):
+    out, at = [], 0
+    for (h, w) in shapes:
+        n = h * w * a
+        out.append(flat[:, at:at + n].reshape(flat.shape[0], h, w, a * last).transpose(0, 3, 1, 2))
+        at += n
+    return out
+
+
+@pytest.mark.parametrize("size,c,from_logits", [((96, 128), 8, False), ((64, 64), 5, True),
+                                                ((256, 256), 80, True)])
+def test_loss_on_head_layout(rh, size, c, from_logits):
+    """forward_levels on [B, A*C, H, W] per level == the flat path on the permuted/concatenated
+    tensors (gradients bit for bit, element by element), and == the oracle."""
+    rng = np.random.default_rng(5 + c)
+    h, w = size
+    anc = O.anchors_for_image(h, w)
+    shapes = [((h + 2 ** l - 1) // 2 ** l, (w + 2 ** l - 1) // 2 ** l) for l in (3, 4, 5, 6, 7)]
+    a, bsz, m = 9, 2, 6
+    assert anc.shape[1] == a * sum(x * y for x, y in shapes)
+    z = [rng.normal(-4.595, 2.0, (bsz, a * c, y, x)).astype(np.float32) for (y, x) in shapes]
+    cls_lv = z if from_logits else [(1.0 / (1.0 + np.exp(-t))).astype(np.float32) for t in z]
+    reg_lv = [rng.normal(0, 1, (bsz, a * 4, y, x)).astype(np.float32) for (y, x) in shapes]
+    ann = -np.ones((bsz, m, 5), np.float32)
+    for j in range(bsz):
+        v = 4 + j
+        x1, y1 = rng.uniform(0, w - 40, v), rng.uniform(0, h - 40, v)
+        ann[j, :v, :4] = np.stack([x1, y1, x1 + rng.uniform(16, 40, v), y1 + rng.uniform(16, 40, v)], 1)
+        ann[j, :v, 4] = rng.integers(0, c, v)
+    cls_flat, reg_flat = flat_from_levels(cls_lv, a, c), flat_from_levels(reg_lv, a, 4)
+
+    tc = [dev(t).requires_grad_(True) for t in cls_lv]
+    tr = [dev(t).requires_grad_(True) for t in reg_lv]
+    mod = rh.FocalLoss(from_logits=from_logits)
+    out = mod.forward_levels(tc, tr, dev(anc), dev(ann))
+    (out["classification_loss"] + out["regression_loss"]).sum().backward()
+
+    flat = rh.functional.focal_loss_fwd_bwd(dev(cls_flat), dev(reg_flat), dev(anc), dev(ann),
+                                            from_logits=from_logits)
+    assert np.array_equal(mod.last["num_pos"].cpu().numpy(), flat["num_pos"].cpu().numpy())
+    assert int(flat["num_pos"].sum()) > 0
+    assert np.allclose(out["classification_loss"].item(), flat["losses"][0].item(), rtol=1e-6)
+    assert np.allclose(out["regression_loss"].item(), flat["losses"][1].item(), rtol=1e-6)
+    want_c = levels_from_flat(flat["d_classifications"].cpu().numpy(), shapes, a, c)
+    want_r = levels_from_flat(flat["d_regressions"].cpu().numpy(), shapes, a, 4)
+    for l in range(len(shapes)):
+        assert np.array_equal(tc[l].grad.cpu().numpy(), want_c[l]), l
+        assert np.array_equal(tr[l].grad.cpu().numpy(), want_r[l]), l
+    ref = O.focal_loss_fwd_bwd(cls_flat, reg_flat, anc, ann, from_logits=from_logits)
+    assert np.allclose(out["classification_loss"].item(), ref["classification_loss"][0], rtol=RTOL)
+    assert np.allclose(out["regression_loss"].item(), ref["regression_loss"][0], rtol=RTOL)
+
+
 def test_loss_deterministic_and_unaligned(rh):
     cls, reg, anc, ann = make_batch(3, 2, 128, 80, 5, [5, 2])
     a = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))

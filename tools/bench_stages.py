@@ -15,7 +15,7 @@ import bench  # noqa: E402
 import retinahead as rh  # noqa: E402
 from retinahead import _lib, functional as F  # noqa: E402
 
-CFG = {2: (16, 608, 80, 20), 3: (8, 800, 601, 8), 4: (4, 1024, 80, 256)}
+CFG = {1: (16, 512, 80, 20), 2: (16, 608, 80, 20), 3: (8, 800, 601, 8), 4: (4, 1024, 80, 256)}
 
 
 def main():
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--infer", action="store_true")
     ap.add_argument("--logits", action="store_true", help="loss on logits (sigmoid folded in)")
+    ap.add_argument("--levels", action="store_true", help="loss on the heads' [B, A*C, H, W] outputs")
     a = ap.parse_args()
     bsz, size, c, m = CFG[a.cfg]
     dev = torch.device("cuda:0")
@@ -37,6 +38,28 @@ def main():
         cls, reg, ann = (torch.from_numpy(x).to(dev) for x in (cls_np, reg_np, ann_np))
         if a.logits:
             cls = torch.logit(cls.double()).float().contiguous()
+        if a.levels:
+            shapes = [((size + 2 ** l - 1) // 2 ** l,) * 2 for l in (3, 4, 5, 6, 7)]
+            cls_lv, reg_lv, at = [], [], 0
+            for (h, w) in shapes:
+                k = h * w * 9
+                cls_lv.append(cls[:, at:at + k].reshape(bsz, h, w, 9 * c).permute(0, 3, 1, 2).contiguous())
+                reg_lv.append(reg[:, at:at + k].reshape(bsz, h, w, 36).permute(0, 3, 1, 2).contiguous())
+                at += k
+            bufs = F.focal_loss_levels_fwd_bwd(cls_lv, reg_lv, anchors, ann, from_logits=a.logits)
+            print("num_pos", bufs["num_pos"].cpu().numpy().tolist())
+            algo = bsz * n * (8 * c + 48)
+            for name, st in (("assign", _lib.STAGE_ASSIGN), ("stream", _lib.STAGE_STREAM),
+                             ("finalize", _lib.STAGE_FINALIZE), ("all", _lib.STAGE_ALL)):
+                fn = lambda: F.focal_loss_levels_fwd_bwd(cls_lv, reg_lv, anchors, ann, stages=st, out=bufs,
+                                                         from_logits=a.logits)
+                for _ in range(10):
+                    fn()
+                mean, mn = bench.event_times(fn, a.iters)
+                extra = f"  algo {algo / mean / 1e6:8.1f} GB/s (mean) {algo / mn / 1e6:8.1f} (min)" \
+                    if name in ("stream", "all") else ""
+                print(f"{name:9s} mean {mean * 1e3:8.1f} us  min {mn * 1e3:8.1f} us{extra}")
+            return
         bufs = F.focal_loss_fwd_bwd(cls, reg, anchors, ann, from_logits=a.logits)
         print("num_pos", bufs["num_pos"].cpu().numpy().tolist())
         algo = bsz * n * (8 * c + 48)
