@@ -714,8 +714,10 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int u = v4 ? s0 + tid * 4 + k : s0 + tid + k * kLvlThreads;
-    ok[k] = u < units;                         // a dead unit loads and stores nothing
-    const int uc = min(u, units - 1);
+    ok[k] = u < units;                         // a dead unit stores nothing, and loads from
+    // a valid stand-in: the level's last unit, or on the float4 path (units is a multiple of
+    // 4 there) the last aligned group of four, so that no access leaves the tensor
+    const int uc = ok[k] ? u : (v4 ? units - 4 + k : units - 1);
     cd[k] = ok[k] ? cplane[uc] : kCodeNeg;
     const int a = uc / hw;
     cell[k] = uc - a * hw;

@@ -15,7 +15,7 @@ import bench  # noqa: E402
 import retinahead as rh  # noqa: E402
 from retinahead import _lib, functional as F  # noqa: E402
 
-CFG = {1: (16, 512, 80, 20), 2: (16, 608, 80, 20), 3: (8, 800, 601, 8), 4: (4, 1024, 80, 256)}
+CFG = {5: (128, 256, 80, 20), 1: (16, 512, 80, 20), 2: (16, 608, 80, 20), 3: (8, 800, 601, 8), 4: (4, 1024, 80, 256)}
 
 
 def main():
