@@ -658,6 +658,7 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
 // which matters: a workgroup lives for a few memory latencies whatever it carries.
 // partials layout: [B][gridDim.x * gridDim.y][2].
 // ---------------------------------------------------------------------------
+constexpr int kLvlPlanes = 5;          // class planes loaded together
 constexpr int kLvlThreads = 256;
 constexpr int kLvlChunk = 4 * kLvlThreads;   // units per workgroup: 4 per thread
 
@@ -702,15 +703,10 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
   const int units = A * hw;
   const int s0 = ((int)blockIdx.x - lt.chunk_begin[l]) * kLvlChunk;
   const bool v4 = lt.vec4[l] != 0;
-  const int np = sum_blk_pos(blk_pos, nblk, j, s_tmp);
-  const float sc = gcls / ((float)max(np, 1) * divisor);
-  const float rsc = greg / ((4.0f * (float)np) * divisor);
 
   // my four units: consecutive (float4 path) or strided by the block size (scalar path)
-  const int* cplane = code + (size_t)j * N + lt.anchor_off[l];
-  int cd[4], cell[4], base_c[4], base_r[4];
+  int cell[4], base_c[4], base_r[4], ucl[4];
   bool ok[4];
-  bool special = false;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int u = v4 ? s0 + tid * 4 + k : s0 + tid + k * kLvlThreads;
@@ -718,14 +714,49 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
     // a valid stand-in: the level's last unit, or on the float4 path (units is a multiple of
     // 4 there) the last aligned group of four, so that no access leaves the tensor
     const int uc = ok[k] ? u : (v4 ? units - 4 + k : units - 1);
-    cd[k] = ok[k] ? cplane[uc] : kCodeNeg;
+    ucl[k] = uc;
     const int a = uc / hw;
     cell[k] = uc - a * hw;
     // offsets of the unit inside image j's [A*C, HW] / [A*4, HW] blocks, class / coordinate 0
     base_c[k] = a * C * hw + cell[k];
     base_r[k] = a * 4 * hw + cell[k];
+  }
+  const float* cp = lt.cls[l] + (size_t)j * A * C * hw;
+  float* dcp = lt.dcls[l] + (size_t)j * A * C * hw;
+  constexpr int U = kLvlPlanes;
+  // The class planes are loaded U at a time, and the first batch goes out before anything else:
+  // nothing it needs depends on the codes or the positive count, and a workgroup only lives
+  // for a few memory latencies, so putting those loads behind the data loads instead of in
+  // front of them takes a whole latency off its life.
+  float in[U][4];
+  auto load_planes = [&](const int c0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t co = (size_t)min(c0 + u, C - 1) * hw;
+      if (v4) {
+        const v4f val = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cp + base_c[0] + co));
+        in[u][0] = val.x; in[u][1] = val.y; in[u][2] = val.z; in[u][3] = val.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in[u][k] = cp[base_c[k] + co];
+      }
+    }
+  };
+  load_planes(c_lo);
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int* cplane = code + (size_t)j * N + lt.anchor_off[l];
+  int cd[4];
+  bool special = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cd[k] = cplane[ucl[k]];
+    if (!ok[k]) cd[k] = kCodeNeg;
     special |= cd[k] != kCodeNeg;
   }
+  const int np = sum_blk_pos(blk_pos, nblk, j, s_tmp);
+  const float sc = gcls / ((float)max(np, 1) * divisor);
+  const float rsc = greg / ((4.0f * (float)np) * divisor);
   // decide per wave, not per lane: a wave with a single positive or ignored unit would
   // otherwise run both element paths one after the other
   special = __ballot(special) != 0ull;
@@ -769,57 +800,47 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
   }
 
   // ---- classification planes c_lo .. c_hi-1 of every unit
-  const float* cp = lt.cls[l] + (size_t)j * A * C * hw;
-  float* dcp = lt.dcls[l] + (size_t)j * A * C * hw;
   const float k0l = -(1.0f - fc.alpha) * kLn2, k0g = -(1.0f - fc.alpha) * sc;
-  constexpr int U = 4;
   for (int c0 = c_lo; c0 < c_hi; c0 += U) {
-    float in[U][4];
-    // loads first, all unconditional (class and unit indices clamped)
+    float out[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t co = (size_t)min(c0 + u, C - 1) * hw;
-      if (v4) {
-        const v4f val = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cp + base_c[0] + co));
-        in[u][0] = val.x; in[u][1] = val.y; in[u][2] = val.z; in[u][3] = val.w;
+      const int c = c0 + u;
+      if (!special) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lk = focal_zero_in<kLogits>(in[u][k], fc, k0l, k0g, out[u][k]);
+          cl += (ok[k] && c < c_hi) ? lk : 0.f;
+        }
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) in[u][k] = cp[base_c[k] + co];
+        for (int k = 0; k < 4; ++k) {
+          const bool one = cd[k] >= 0 && (cd[k] & 0xFFFF) == c;
+          const bool live = cd[k] != kCodeIgn && ok[k] && c < c_hi;
+          float gk;
+          const float lk = focal_any_in<kLogits>(in[u][k], one, fc, sc, gk);
+          out[u][k] = live ? gk : 0.f;
+          cl += live ? lk : 0.f;
+        }
       }
     }
+    // next batch on its way before this one is stored
+    if (c0 + U < c_hi) load_planes(c0 + U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u;
       if (c < c_hi) {
-        float out[4];
-        if (!special) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float lk = focal_zero_in<kLogits>(in[u][k], fc, k0l, k0g, out[k]);
-            cl += ok[k] ? lk : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bool one = cd[k] >= 0 && (cd[k] & 0xFFFF) == c;
-            const bool live = cd[k] != kCodeIgn && ok[k];
-            float gk;
-            const float lk = focal_any_in<kLogits>(in[u][k], one, fc, sc, gk);
-            out[k] = live ? gk : 0.f;
-            cl += live ? lk : 0.f;
-          }
-        }
         const size_t co = (size_t)c * hw;
         if (v4) {
           if (ok[0]) {
             v4f o;
-            o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+            o.x = out[u][0]; o.y = out[u][1]; o.z = out[u][2]; o.w = out[u][3];
             __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(dcp + base_c[0] + co));
           }
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (ok[k]) dcp[base_c[k] + co] = out[k];
+            if (ok[k]) dcp[base_c[k] + co] = out[u][k];
         }
       }
     }
@@ -1025,9 +1046,10 @@ static int make_level_plan(int num_levels, const int32_t* heights, const int32_t
   return RH_OK;
 }
 
-// Workgroups that share the class planes of one (image, anchor, chunk): about 16 planes each.
+// Workgroups that share the class planes of one (image, chunk of units): about 10 planes each,
+// two batches of kLvlPlanes (measured best at C = 80 among 5, 8, 10, 16 and 32 planes).
 static int level_csplit(int c) {
-  int s = c / 16;
+  int s = c / 10;
   return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
