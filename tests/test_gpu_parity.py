@@ -408,6 +408,24 @@ def test_postprocess_agnostic(rh):
     assert len(tup) == 3 and torch.equal(tup[0], res[0]["scores"])
 
 
+def test_postprocess_dense_tiles_and_image_borders(rh):
+    """Candidate lists with full 64-row tiles, candidates on both sides of the tile that two
+    images share, equal scores, and a capacity that is met exactly."""
+    cls, reg, anc = infer_batch(5, 3, 256, 20, mu=-9.0)
+    n = anc.shape[1]
+    assert n % 64 != 0                                   # images share tiles
+    cls[0, 1000:1200, 7] = 0.9                           # 200 consecutive candidates, equal scores
+    cls[0, -5:, 3] = 0.8                                 # last rows of image 0 ...
+    cls[1, :5, 4] = 0.7                                  # ... and first rows of image 1: one tile
+    cls[2, 64:128, :] = 0.6                              # one full tile, all classes tied -> label 0
+    res = check_post(rh, cls, reg, anc, 256)
+    assert (res[2]["labels"][res[2]["scores"] == 0.6] == 0).all()
+    cnt = [int((cls[b].max(axis=1) > 0.05).sum()) for b in range(3)]
+    check_post(rh, cls, reg, anc, 256, max_candidates=max(cnt))           # exactly full
+    check_post(rh, cls, reg, anc, 256, max_candidates=max(cnt) - 1)       # one short: second pass
+    check_post(rh, cls, reg, anc, 256, mode="per_class", pre_nms_topk=150)
+
+
 def test_sigmoid_and_postprocess_on_logits(rh):
     """The logits-in post-processing equals the probability form applied to the library's own
     float32 sigmoid, bit for bit; that sigmoid is within a few ulp of numpy's / the oracle's."""
