@@ -135,14 +135,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
                          f"(WORLD_SIZE={world})")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; RH_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the
+    # multi-rank path on a one-GPU box (RCCL refuses two ranks on the same device)
+    backend = os.environ.get("RH_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import retinahead as rh
     from retinahead import _lib, functional as F
     rh.load_library()
+    verbose = bool(os.environ.get("RH_BENCH_VERBOSE"))
+
+    def note(msg):
+        if verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     img = torch.zeros(1, 3, SIZE, SIZE, device=dev)
     anchors = rh.Anchors()(img)
@@ -202,9 +214,13 @@ def main():
             out = local_step()
         if world > 1:
             vec = torch.cat([out["classification_loss"].detach(), out["regression_loss"].detach()])
-            pending.append((vec, dist.all_reduce(vec, op=dist.ReduceOp.SUM, async_op=True)))
-            if len(pending) > 4:                 # bounded backlog; values are the global losses
-                pending.pop(0)[1].wait()
+            if backend == "nccl":
+                pending.append((vec, dist.all_reduce(vec, op=dist.ReduceOp.SUM, async_op=True)))
+                if len(pending) > 4:             # bounded backlog; values are the global losses
+                    pending.pop(0)[1].wait()
+            else:                                # rehearsal backends: blocking, through the host
+                host = vec.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
         return out
 
     def fence():
@@ -215,16 +231,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"launch mode: {launch}")
     for _ in range(args.warmup):
         out = step()
+    note("warm-up enqueued")
     fence()
+    note("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
+    note(f"timed region done: {elapsed:.4f} s")
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     anchors_per_s = world * BATCH * n * args.steps / elapsed
