@@ -267,6 +267,24 @@ int rh_postprocess(const float* classifications, const float* regressions, const
                    int32_t* cand_count, int32_t* overflow, void* workspace,
                    size_t workspace_bytes, int32_t stages, rh_stream_t stream);
 
+/* The same post-processing on the heads' own outputs: per pyramid level l a classification tensor
+ * [B, A*C, H_l, W_l] and a regression tensor [B, A*4, H_l, W_l], instead of the flat tensors the
+ * reference builds from them (models/retinanet/model.py:152-154, 196-202, 311-313).  Results are
+ * identical to rh_postprocess on the flattened tensors.  cls_levels / reg_levels, heights, widths:
+ * HOST arrays [num_levels <= 8]; anchors device [N,4], N = A * sum_l H_l*W_l; everything else as
+ * rh_postprocess. */
+size_t rh_postprocess_levels_workspace_bytes(int32_t batch, int32_t num_levels,
+                                             const int32_t* heights, const int32_t* widths,
+                                             int32_t anchors_per_cell, int32_t num_classes,
+                                             const rh_post_params* params);
+int rh_postprocess_levels(const float* const* cls_levels, const float* const* reg_levels,
+                          const float* anchors, int32_t batch, int32_t num_levels,
+                          const int32_t* heights, const int32_t* widths, int32_t anchors_per_cell,
+                          int32_t num_classes, const rh_post_params* params, float* out_scores,
+                          int64_t* out_labels, float* out_boxes, int32_t* out_count,
+                          int32_t* cand_count, int32_t* overflow, void* workspace,
+                          size_t workspace_bytes, int32_t stages, rh_stream_t stream);
+
 enum rh_post_stage {
   RH_POST_DECODE = 1, /* class max + threshold + decode + clip + compaction */
   RH_POST_SORT = 2,   /* per-image sort by (score desc, anchor index asc)   */

@@ -81,6 +81,35 @@ __global__ __launch_bounds__(kThreads) void clip_boxes_kernel(float4* __restrict
   boxes[i] = clip_box(boxes[i], width, height);
 }
 
+// Geometry of the per-level head tensors (see score_scan_levels_kernel).
+constexpr int kMaxLevels = 8;
+constexpr int kLvlChunk = 1024;    // anchor-cells per workgroup of the level scan = 16 tile lists
+struct LevelGeom {
+  const float* cls[kMaxLevels];    // [B, A*C, H, W]
+  const float* reg[kMaxLevels];    // [B, A*4, H, W]
+  int hw[kMaxLevels];
+  int anchor_off[kMaxLevels + 1];  // first anchor of each level, then N
+  int chunk_begin[kMaxLevels + 1];
+  int vec4[kMaxLevels];
+  int num_levels;
+  int a;                           // anchors per cell
+  // anchor n -> level, anchor slot, cell
+  __device__ __forceinline__ void locate(const int n, int& l, int& as, int& cell) const {
+    l = 0;
+    while (l + 1 < num_levels && n >= anchor_off[l + 1]) ++l;
+    const int r = n - anchor_off[l];
+    cell = r / a;
+    as = r - cell * a;
+  }
+  // tile list (within the image) that holds anchor n's candidate
+  __device__ __forceinline__ int tile_of(const int n) const {
+    int l, as, cell;
+    locate(n, l, as, cell);
+    const int u = as * hw[l] + cell;
+    return (chunk_begin[l] + u / kLvlChunk) * (kLvlChunk / 64) + (u % kLvlChunk) / 64;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Score scan: per anchor row the maximum over classes and its first arg-max
 // (model.py:323), kept only where it exceeds the score threshold (model.py:325).
@@ -221,6 +250,129 @@ __global__ __launch_bounds__(kThreads) void score_scan_rows_kernel(const float* 
   if (threadIdx.x < kTileRows) emit_tile(tile, rows, row0, s_best, thresh, tc);
 }
 
+// ---------------------------------------------------------------------------
+// Score scan on the classification head's own outputs: per pyramid level a tensor
+// [B, A*C, H, W], which the reference permutes, reshapes and concatenates into [B, N, C]
+// (model.py:196-202, 311-313) before taking the class maximum (model.py:323).  Work unit
+// u = a*HW + cell of a level; a workgroup owns 1024 consecutive units of one image (4 per
+// thread) and walks all C class planes of them, each a contiguous run of cells, keeping the
+// running (maximum, first arg-max) in registers: no atomics.  Candidates go to the same kind
+// of tile lists as in the flat scan, one list per 64 consecutive units, with the key built on
+// the flat row index b*N + n (n = off_l + cell*A + a) so that everything downstream (ties by
+// anchor index, decode, outputs) is identical to the flat path.
+// kLogits as in score_scan_tile_kernel.
+// ---------------------------------------------------------------------------
+template <bool kLogits>
+__global__ __launch_bounds__(kThreads) void score_scan_levels_kernel(LevelGeom lv, TileCands tc,
+                                                                     int N, int C, float thresh,
+                                                                     float pre) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.y;
+  int l = 0;
+  while (l + 1 < lv.num_levels && (int)blockIdx.x >= lv.chunk_begin[l + 1]) ++l;
+  const int hw = lv.hw[l], A = lv.a;
+  const int units = A * hw;
+  const int s0 = ((int)blockIdx.x - lv.chunk_begin[l]) * kLvlChunk;
+  const bool v4 = lv.vec4[l] != 0;
+  const float* cp = lv.cls[l] + (size_t)j * A * C * hw;
+
+  int base_c[4], un[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int u = v4 ? s0 + tid * 4 + k : s0 + tid + k * kThreads;
+    ok[k] = u < units;
+    // dead units load from a valid stand-in (on the float4 path the last aligned group of four)
+    const int uc = ok[k] ? u : (v4 ? units - 4 + k : units - 1);
+    un[k] = uc;
+    const int a = uc / hw;
+    base_c[k] = a * C * hw + (uc - a * hw);
+  }
+  float best[4];
+  int bcls[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    best[k] = -INFINITY;
+    bcls[k] = 0;
+  }
+  constexpr int U = 8;
+  for (int c0 = 0; c0 < C; c0 += U) {
+    float in[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t co = (size_t)min(c0 + u, C - 1) * hw;
+      if (v4) {
+        const v4f val = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cp + base_c[0] + co));
+        in[u][0] = val.x; in[u][1] = val.y; in[u][2] = val.z; in[u][3] = val.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in[u][k] = cp[base_c[k] + co];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u;
+      if (c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // only values over the threshold can matter; strict > keeps the first maximum
+          if (in[u][k] > (kLogits ? pre : thresh)) {
+            const float pv = kLogits ? sigmoid_f32(in[u][k]) : in[u][k];
+            if (pv > best[k]) {
+              best[k] = pv;
+              bcls[k] = c;
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- emit: one list per 64 consecutive units
+  const int tiles_per_image = lv.chunk_begin[lv.num_levels] * (kLvlChunk / 64);
+  const int tile0 = j * tiles_per_image + (int)blockIdx.x * (kLvlChunk / 64);
+  bool cand[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cand[k] = ok[k] && best[k] > thresh;
+  if (v4) {
+    // a thread's units are consecutive; 16 lanes make one tile
+    const int mine = (int)cand[0] + (int)cand[1] + (int)cand[2] + (int)cand[3];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int o = __shfl_up(incl, d, 16);
+      if ((lane & 15) >= d) incl += o;
+    }
+    const int tile = tile0 + wave * 4 + (lane >> 4);
+    int slot = incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (cand[k]) {
+        const int a = un[k] / hw;
+        const unsigned n = (unsigned)(lv.anchor_off[l] + (un[k] - a * hw) * A + a);
+        const size_t at = tc.at(tile, slot++);
+        tc.key[at] = make_key(best[k], (unsigned)j * (unsigned)N + n);
+        tc.lab[at] = bcls[k];
+      }
+    }
+    if ((lane & 15) == 15) tc.cnt[tile] = incl;
+  } else {
+    // units strided by the block size: for each k a wave covers one tile
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u64 m = __ballot(cand[k]);
+      const int tile = tile0 + k * (kThreads / 64) + wave;
+      if (cand[k]) {
+        const int a = un[k] / hw;
+        const unsigned n = (unsigned)(lv.anchor_off[l] + (un[k] - a * hw) * A + a);
+        const size_t at = tc.at(tile, __popcll(m & ((1ull << lane) - 1ull)));
+        tc.key[at] = make_key(best[k], (unsigned)j * (unsigned)N + n);
+        tc.lab[at] = bcls[k];
+      }
+      if (lane == 0) tc.cnt[tile] = __popcll(m);
+    }
+  }
+}
+
 // out = sigmoid_f32(x): the probabilities the logits-in modes work with.
 __global__ __launch_bounds__(kThreads) void sigmoid_kernel(const float* __restrict__ x,
                                                            float* __restrict__ out, long long count) {
@@ -256,7 +408,35 @@ struct SortSrc {
   int N;
   int count;
   int from_tiles;
+  // head layout (from_tiles != 0 and tiles_per_image > 0): image j owns the tile lists
+  // [j*T, (j+1)*T), which are NOT in anchor order, and regressions are the per-level tensors
+  // [B, A*4, H, W] of `lv`
+  int tiles_per_image;
+  LevelGeom lv;
 };
+
+// First and last tile list of image j.
+__device__ __forceinline__ void image_tiles(const SortSrc& src, const int j, int& t_lo, int& t_hi) {
+  if (src.tiles_per_image > 0) {
+    t_lo = j * src.tiles_per_image;
+    t_hi = t_lo + src.tiles_per_image - 1;
+  } else {
+    const long long first = (long long)j * src.N;
+    t_lo = (int)(first >> 6);
+    t_hi = (int)((first + src.N - 1) >> 6);
+  }
+}
+
+// Regression deltas of anchor n of image j.
+__device__ __forceinline__ float4 load_deltas(const SortSrc& src, const int j, const unsigned n,
+                                              const unsigned idx) {
+  if (src.tiles_per_image == 0) return src.reg[idx];
+  int l, a, cell;
+  src.lv.locate((int)n, l, a, cell);
+  const int hw = src.lv.hw[l];
+  const float* r = src.lv.reg[l] + ((size_t)j * src.lv.a + a) * 4 * hw + cell;
+  return make_float4(r[0], r[hw], r[2 * (size_t)hw], r[3 * (size_t)hw]);
+}
 
 __device__ __forceinline__ int next_pow2(int v) {
   int p = 1;
@@ -269,7 +449,8 @@ __device__ __forceinline__ int next_pow2(int v) {
 __device__ __forceinline__ int gather_image_keys(const int j, const SortSrc src, u64* dst,
                                                  const int cap, int* s_count) {
   const long long first = (long long)j * src.N, last = first + src.N - 1;
-  const int t_lo = (int)(first >> 6), t_hi = (int)(last >> 6);
+  int t_lo, t_hi;
+  image_tiles(src, j, t_lo, t_hi);
   if (threadIdx.x == 0) *s_count = 0;
   __syncthreads();
   for (int t = t_lo + (int)threadIdx.x; t <= t_hi; t += (int)blockDim.x) {
@@ -307,8 +488,11 @@ __device__ __forceinline__ void store_sorted(const u64 key, const int i, const i
   const unsigned idx = key_index(key);
   if (src.from_tiles) {
     const unsigned n = idx - (unsigned)j * (unsigned)src.N;
-    sbox[i] = clip_box(decode_box(src.anchors[n], src.reg[idx], src.bc), src.width, src.height);
-    const unsigned t = idx >> 6;
+    sbox[i] = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
+                       src.height);
+    const unsigned t = src.tiles_per_image > 0
+                           ? (unsigned)(j * src.tiles_per_image + src.lv.tile_of((int)n))
+                           : idx >> 6;
     const int c = src.tc.cnt[t];
     int lab = 0;
     for (int r = 0; r < c; ++r)
@@ -461,7 +645,8 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
   if (src.from_tiles) {
     const TileCands tc = src.tc;
     const long long first = (long long)j * src.N, last = first + src.N - 1;
-    const int t_lo = (int)(first >> 6), t_hi = (int)(last >> 6);
+    int t_lo, t_hi;
+    image_tiles(src, j, t_lo, t_hi);
     // Wave w compacts a contiguous range of the image's tiles, 64 tiles (one per lane) at a
     // time, so list loads are coalesced.  Loads are unconditional (tile and slot indices
     // clamped) and issued kRankBatch x kRankSlots at a time ahead of their use: a chain of
@@ -584,9 +769,14 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
   // wave w counts in [q0, q1): equal shares of the list, multiples of 8 entries
   const int seg = ((K + 8 * kRankWaves - 1) / (8 * kRankWaves)) << 3;
   const int q0 = min(wave * seg, K), q1 = min(q0 + seg, K);
-  int rank = rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx);
-  rank += rank_count<2>(s_sk, s_ix, max(q0, p0), min(q1, p0 + kRankKeys), mys, myx);
-  rank += rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx);
+  int rank;
+  if (src.from_tiles && src.tiles_per_image > 0) {
+    rank = rank_count<2>(s_sk, s_ix, q0, q1, mys, myx);      // list not in anchor order: full keys
+  } else {
+    rank = rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx);
+    rank += rank_count<2>(s_sk, s_ix, max(q0, p0), min(q1, p0 + kRankKeys), mys, myx);
+    rank += rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx);
+  }
   s_part[wave][lane] = rank;
   __syncthreads();
   if (wave == 0) {
@@ -599,7 +789,8 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
       const unsigned idx = 0xFFFFFFFFu - myx;
       if (src.from_tiles) {
         const unsigned n = idx - (unsigned)j * (unsigned)src.N;
-        sbox[o] = clip_box(decode_box(src.anchors[n], src.reg[idx], src.bc), src.width, src.height);
+        sbox[o] = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
+                           src.height);
       } else {
         sbox[o] = src.boxes[idx];
       }
@@ -1334,6 +1525,117 @@ int rh_postprocess(const float* classifications, const float* regressions, const
     src.height = q->height;
     src.N = (int)n;
     src.from_tiles = 1;
+    if (int e = launch_sort(p, w, q->pre_nms_topk, src, s)) return e;
+  }
+  if (stages & RH_POST_NMS) {
+    SweepOut out{};
+    out.scores = out_scores;
+    out.labels = reinterpret_cast<long long*>(out_labels);
+    out.boxes = reinterpret_cast<float4*>(out_boxes);
+    out.count = out_count;
+    out.out_stride = out_cap;
+    out.max_keep = out_cap;
+    out.counters = w.counters;
+    out.cand_out = cand_count;
+    out.ovf_out = overflow;
+    out.batch = batch;
+    if (int e = launch_nms(p, w, q->iou_thresh, q->per_class, out, s)) return e;
+  }
+  return RH_OK;
+}
+
+static int make_level_geom(int num_levels, const int32_t* heights, const int32_t* widths, int a,
+                           LevelGeom* g, long long* n_out) {
+  RH_REQUIRE(num_levels >= 1 && num_levels <= kMaxLevels, RH_ESHAPE, "num_levels=%d not in [1, %d]",
+             num_levels, kMaxLevels);
+  RH_REQUIRE(heights && widths, RH_EINVAL, "null level shapes");
+  RH_REQUIRE(a >= 1 && a <= 65535, RH_ESHAPE, "anchors_per_cell=%d out of range", a);
+  long long cells = 0;
+  int chunks = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    RH_REQUIRE(heights[l] >= 1 && widths[l] >= 1, RH_ESHAPE, "level %d has shape %d x %d", l,
+               heights[l], widths[l]);
+    const long long hw = (long long)heights[l] * widths[l];
+    RH_REQUIRE(hw * a < (1ll << 31) && (cells + hw) * a < (1ll << 31), RH_ESHAPE, "levels too large");
+    g->hw[l] = (int)hw;
+    g->anchor_off[l] = (int)(cells * a);
+    g->chunk_begin[l] = chunks;
+    chunks += (int)((hw * a + kLvlChunk - 1) / kLvlChunk);
+    cells += hw;
+  }
+  g->anchor_off[num_levels] = (int)(cells * a);
+  g->chunk_begin[num_levels] = chunks;
+  g->num_levels = num_levels;
+  g->a = a;
+  *n_out = cells * a;
+  return RH_OK;
+}
+
+size_t rh_postprocess_levels_workspace_bytes(int32_t batch, int32_t num_levels,
+                                             const int32_t* heights, const int32_t* widths,
+                                             int32_t anchors_per_cell, int32_t num_classes,
+                                             const rh_post_params* params) {
+  LevelGeom g{};
+  long long n = 0;
+  if (make_level_geom(num_levels, heights, widths, anchors_per_cell, &g, &n)) return 0;
+  if (check_post(batch, n, num_classes, params)) return 0;
+  const NmsPlan p = make_plan(batch, params->cand_cap, params->pre_nms_topk);
+  return carve_post(nullptr, p, (long long)batch * g.chunk_begin[num_levels] * (kLvlChunk / 64)).bytes;
+}
+
+int rh_postprocess_levels(const float* const* cls_levels, const float* const* reg_levels,
+                          const float* anchors, int32_t batch, int32_t num_levels,
+                          const int32_t* heights, const int32_t* widths, int32_t anchors_per_cell,
+                          int32_t num_classes, const rh_post_params* q, float* out_scores,
+                          int64_t* out_labels, float* out_boxes, int32_t* out_count,
+                          int32_t* cand_count, int32_t* overflow, void* workspace,
+                          size_t workspace_bytes, int32_t stages, rh_stream_t stream) {
+  LevelGeom g{};
+  long long n = 0;
+  if (int e = make_level_geom(num_levels, heights, widths, anchors_per_cell, &g, &n)) return e;
+  if (int e = check_post(batch, n, num_classes, q)) return e;
+  RH_REQUIRE(cls_levels && reg_levels && anchors && out_scores && out_labels && out_boxes && out_count,
+             RH_EINVAL, "null pointer");
+  RH_REQUIRE(aligned16(anchors) && aligned16(out_boxes), RH_EALIGN,
+             "anchors and out_boxes must be 16-byte aligned");
+  RH_REQUIRE((stages & ~RH_POST_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
+  for (int l = 0; l < num_levels; ++l) {
+    RH_REQUIRE(cls_levels[l] && reg_levels[l], RH_EINVAL, "null pointer for level %d", l);
+    g.cls[l] = cls_levels[l];
+    g.reg[l] = reg_levels[l];
+    g.vec4[l] = g.hw[l] % 4 == 0 && aligned16(cls_levels[l]);
+  }
+  const int chunks = g.chunk_begin[num_levels];
+  const int tiles_per_image = chunks * (kLvlChunk / 64);
+  const long long num_tiles = (long long)batch * tiles_per_image;
+  RH_REQUIRE(num_tiles < (1ll << 31), RH_ESHAPE, "too many tile lists");
+  const NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
+  const size_t need = carve_post(nullptr, p, num_tiles).bytes;
+  RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
+             "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const PostWorkspace w = carve_post(workspace, p, num_tiles);
+  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab, (int)num_tiles};
+  const int out_cap = q->max_det > 0 ? q->max_det : p.box_cap;
+
+  if (stages & RH_POST_DECODE) {
+    auto kern = q->from_logits ? score_scan_levels_kernel<true> : score_scan_levels_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(chunks, batch), dim3(kThreads), 0, s, g, tc, (int)n, num_classes,
+                       q->score_thresh, logit_prefilter(q->score_thresh));
+    RH_CHECK_LAUNCH("score_scan_levels_kernel");
+  }
+  if (stages & RH_POST_SORT) {
+    SortSrc src{};
+    src.tc = tc;
+    src.anchors = reinterpret_cast<const float4*>(anchors);
+    src.bc = make_coder(nullptr, nullptr);
+    src.width = q->width;
+    src.height = q->height;
+    src.N = (int)n;
+    src.from_tiles = 1;
+    src.tiles_per_image = tiles_per_image;
+    src.lv = g;
     if (int e = launch_sort(p, w, q->pre_nms_topk, src, s)) return e;
   }
   if (stages & RH_POST_NMS) {

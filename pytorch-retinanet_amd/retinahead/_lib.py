@@ -91,6 +91,11 @@ SIGNATURES = {
     "rh_postprocess_workspace_bytes": (_SZ, [_I32, _I64, _I32, C.POINTER(PostParams)]),
     "rh_postprocess": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, C.POINTER(PostParams), _P, _P, _P, _P,
                                  _P, _P, _P, _SZ, _I32, _P]),
+    "rh_postprocess_levels_workspace_bytes": (_SZ, [_I32, _I32, _P, _P, _I32, _I32,
+                                                    C.POINTER(PostParams)]),
+    "rh_postprocess_levels": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _I32, _I32,
+                                        C.POINTER(PostParams), _P, _P, _P, _P, _P, _P, _P, _SZ, _I32,
+                                        _P]),
 }
 
 _lib = None

@@ -458,3 +458,69 @@ def postprocess_raw(classifications, regressions, anchors_t, height, width, scor
             _p(out["labels"]), _p(out["boxes"]), _p(cnt[0]), _p(cnt[1]), _p(cnt[2]), _p(ws),
             ws.numel(), int(stages), _stream(dev)), "rh_postprocess")
     return out
+
+
+def _level_shapes(cls_levels, reg_levels, anc):
+    """Checks per-level head tensors [B, A*C, H, W] / [B, A*4, H, W]; returns (B, A, C, heights, widths)."""
+    if len(cls_levels) != len(reg_levels) or not cls_levels:
+        raise RetinaHeadError("need as many classification as regression levels (at least one)")
+    bsz = cls_levels[0].shape[0]
+    if any(t.dim() != 4 or t.shape[0] != bsz for t in list(cls_levels) + list(reg_levels)):
+        raise RetinaHeadError("level tensors must be [B, channels, H, W]")
+    hs = [int(t.shape[2]) for t in cls_levels]
+    wsz = [int(t.shape[3]) for t in cls_levels]
+    cells = sum(h * w for h, w in zip(hs, wsz))
+    if anc.shape[0] % cells:
+        raise RetinaHeadError(f"{anc.shape[0]} anchors do not divide over {cells} cells")
+    a = anc.shape[0] // cells
+    if cls_levels[0].shape[1] % a:
+        raise RetinaHeadError(f"{cls_levels[0].shape[1]} classification channels with {a} anchors per cell")
+    c = cls_levels[0].shape[1] // a
+    for tc, tr, h, w in zip(cls_levels, reg_levels, hs, wsz):
+        if tuple(tc.shape) != (bsz, a * c, h, w) or tuple(tr.shape) != (bsz, a * 4, h, w):
+            raise RetinaHeadError("inconsistent level shapes")
+    return bsz, a, c, hs, wsz
+
+
+def postprocess_levels_raw(cls_levels, reg_levels, anchors_t, height, width, score_thresh=0.05,
+                           iou_thresh=0.5, per_class=False, pre_nms_topk=0, max_det=0, cand_cap=4096,
+                           stages=_lib.POST_ALL, out=None, from_logits=False):
+    """:func:`postprocess_raw` on the heads' per-level outputs ``[B, A*C, H_l, W_l]`` /
+    ``[B, A*4, H_l, W_l]`` (no permute / view / cat, models/retinanet/model.py:152-154,196-202,
+    311-313).  Same outputs as the flat form."""
+    dev = _dev_check(*cls_levels, *reg_levels, anchors_t)
+    cls = [_f32c(t) for t in cls_levels]
+    reg = [_f32c(t) for t in reg_levels]
+    anc = _anchors2d(anchors_t)
+    bsz, a, c, hs, wsz = _level_shapes(cls, reg, anc)
+    n = anc.shape[0]
+    nl = len(cls)
+    cand_cap = max(1, min(int(cand_cap), n))
+    topk = int(pre_nms_topk or 0)
+    max_det = int(max_det or 0)
+    box_cap = min(cand_cap, topk) if topk > 0 else cand_cap
+    out_cap = max_det if max_det > 0 else box_cap
+    params = _lib.PostParams(float(height), float(width), float(score_thresh), float(iou_thresh),
+                             int(bool(per_class)), topk, max_det, cand_cap, int(bool(from_logits)))
+    lib = _lib.load()
+    if out is None:
+        out = dict(
+            scores=torch.empty((bsz, out_cap), dtype=torch.float32, device=dev),
+            labels=torch.empty((bsz, out_cap), dtype=torch.int64, device=dev),
+            boxes=torch.empty((bsz, out_cap, 4), dtype=torch.float32, device=dev),
+            counts=torch.zeros((3, bsz), dtype=torch.int32, device=dev),
+        )
+    ptrs = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    ints = lambda vs: (C.c_int32 * nl)(*vs)
+    h_arr, w_arr = ints(hs), ints(wsz)
+    need = lib.rh_postprocess_levels_workspace_bytes(bsz, nl, h_arr, w_arr, a, c, C.byref(params))
+    if need == 0:
+        raise RetinaHeadError("postprocess_levels: " + _lib.last_error())
+    ws = workspace(dev, need, "post_levels")
+    cnt = out["counts"]
+    with torch.cuda.device(dev):
+        _lib.check(lib.rh_postprocess_levels(
+            ptrs(cls), ptrs(reg), _p(anc), bsz, nl, h_arr, w_arr, a, c, C.byref(params),
+            _p(out["scores"]), _p(out["labels"]), _p(out["boxes"]), _p(cnt[0]), _p(cnt[1]), _p(cnt[2]),
+            _p(ws), ws.numel(), int(stages), _stream(dev)), "rh_postprocess_levels")
+    return out

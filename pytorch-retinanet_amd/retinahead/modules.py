@@ -267,7 +267,9 @@ def postprocess(classification, regression, anchors, img_batch, score_thresh=0.0
                 output="dicts", from_logits=False):
     """Inference post-processing for the whole batch; replaces models/retinanet/model.py:320-340.
 
-    classification [B,N,C] probabilities, regression [B,N,4], anchors [1,N,4]; ``img_batch`` is the
+    classification [B,N,C] probabilities, regression [B,N,4], anchors [1,N,4] -- or, to skip the
+    permute / view / cat of model.py:152-154,196-202,311-313, lists with the heads' per-level
+    outputs ``[B, A*C, H_l, W_l]`` and ``[B, A*4, H_l, W_l]`` (same results); ``img_batch`` is the
     image tensor [B,3,H,W] (only its shape is read) or an ``(H, W)`` pair.
     mode 'agnostic' is the reference behaviour (one NMS over all classes on the max-class score);
     'per_class' lets only equal labels suppress each other.
@@ -285,12 +287,14 @@ def postprocess(classification, regression, anchors, img_batch, score_thresh=0.0
         height, width = int(img_batch.shape[2]), int(img_batch.shape[3])
     else:
         height, width = int(img_batch[0]), int(img_batch[1])
-    n = classification.shape[1]
+    levels = isinstance(classification, (list, tuple))
+    n = anchors.shape[-2] if levels else classification.shape[1]
+    raw = F.postprocess_levels_raw if levels else F.postprocess_raw
     cap = min(n, int(max_candidates))
     while True:
-        out = F.postprocess_raw(classification, regression, anchors, height, width, score_thresh,
-                                iou_thresh, mode == "per_class", pre_nms_topk or 0, max_det or 0, cap,
-                                from_logits=from_logits)
+        out = raw(classification, regression, anchors, height, width, score_thresh,
+                  iou_thresh, mode == "per_class", pre_nms_topk or 0, max_det or 0, cap,
+                  from_logits=from_logits)
         counts = out["counts"].cpu()          # the one host read: output sizes are data dependent
         if int(counts[2].max()) == 0 or cap >= n:
             break

@@ -426,6 +426,40 @@ def test_postprocess_dense_tiles_and_image_borders(rh):
     check_post(rh, cls, reg, anc, 256, mode="per_class", pre_nms_topk=150)
 
 
+@pytest.mark.parametrize("size,c,from_logits", [((96, 128), 8, False), ((64, 64), 5, True),
+                                                ((256, 256), 80, True)])
+def test_postprocess_on_head_layout(rh, size, c, from_logits):
+    """postprocess on the per-level [B, A*C, H, W] / [B, A*4, H, W] tensors == postprocess on the
+    flat tensors the reference builds from them, bit for bit."""
+    rng = np.random.default_rng(50 + c)
+    h, w = size
+    anc = O.anchors_for_image(h, w)
+    shapes = [((h + 2 ** l - 1) // 2 ** l, (w + 2 ** l - 1) // 2 ** l) for l in (3, 4, 5, 6, 7)]
+    a, bsz = 9, 3
+    mu = -7.5 if c == 80 else -5.0
+    z = [rng.normal(mu, 1.5, (bsz, a * c, y, x)).astype(np.float32) for (y, x) in shapes]
+    if from_logits:
+        z[0][1, :c, :2, :] = 3.0             # a run of equal scores across classes and cells
+        z[0][2] = -20.0                      # image 2: candidates on the coarser levels only
+        cls_lv = z
+    else:
+        cls_lv = [(1.0 / (1.0 + np.exp(-t))).astype(np.float32) for t in z]
+        cls_lv[0][1, :c, :2, :] = 0.95
+        cls_lv[0][2] = 0.0
+    reg_lv = [rng.normal(0, 0.4, (bsz, a * 4, y, x)).astype(np.float32) for (y, x) in shapes]
+    cls_flat, reg_flat = flat_from_levels(cls_lv, a, c), flat_from_levels(reg_lv, a, 4)
+    an = dev(anc)
+    for kw in (dict(), dict(mode="per_class", pre_nms_topk=200), dict(max_candidates=64)):
+        lv = rh.postprocess([dev(t) for t in cls_lv], [dev(t) for t in reg_lv], an, (h, w),
+                            from_logits=from_logits, **kw)
+        fl = rh.postprocess(dev(cls_flat), dev(reg_flat), an, (h, w), from_logits=from_logits, **kw)
+        assert len(lv) == len(fl) == bsz
+        for ra, rb in zip(lv, fl):
+            for k in ("scores", "labels", "boxes"):
+                assert torch.equal(ra[k], rb[k]), (kw, k)
+        assert lv[0]["scores"].numel() > 0 and lv[1]["scores"].numel() > 0
+
+
 def test_sigmoid_and_postprocess_on_logits(rh):
     """The logits-in post-processing equals the probability form applied to the library's own
     float32 sigmoid, bit for bit; that sigmoid is within a few ulp of numpy's / the oracle's."""

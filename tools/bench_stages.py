@@ -76,6 +76,27 @@ def main():
     else:
         icls_np, ireg_np = bench.synth_infer(rng, bsz, n, c)
         icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
+        if a.levels:
+            shapes = [((size + 2 ** l - 1) // 2 ** l,) * 2 for l in (3, 4, 5, 6, 7)]
+            cls_lv, reg_lv, at = [], [], 0
+            for (h, w) in shapes:
+                k = h * w * 9
+                cls_lv.append(icls[:, at:at + k].reshape(bsz, h, w, 9 * c).permute(0, 3, 1, 2).contiguous())
+                reg_lv.append(ireg[:, at:at + k].reshape(bsz, h, w, 36).permute(0, 3, 1, 2).contiguous())
+                at += k
+            res = F.postprocess_levels_raw(cls_lv, reg_lv, anchors, size, size, cand_cap=4096)
+            print("counts", res["counts"].cpu().numpy()[:, :4].tolist())
+            algo = bsz * n * (4 * c + 32)
+            for name, st in (("decode", _lib.POST_DECODE), ("sort", _lib.POST_SORT),
+                             ("nms", _lib.POST_NMS), ("all", _lib.POST_ALL)):
+                fn = lambda: F.postprocess_levels_raw(cls_lv, reg_lv, anchors, size, size, cand_cap=4096,
+                                                      stages=st, out=res)
+                for _ in range(5):
+                    fn()
+                mean, mn = bench.event_times(fn, a.iters)
+                extra = f"  algo {algo / mean / 1e6:8.1f} GB/s" if name in ("decode", "all") else ""
+                print(f"{name:9s} mean {mean * 1e3:8.1f} us  min {mn * 1e3:8.1f} us{extra}")
+            return
         res = F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=4096)
         print("counts", res["counts"].cpu().numpy()[:, :4].tolist())
         algo = bsz * n * (4 * c + 32)
