@@ -302,6 +302,27 @@ def main():
     if os.path.exists(tfile):
         traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
 
+    # ---- the loss on logits and on the heads' own layout (same bytes, same timing method) ----
+    with torch.no_grad():
+        shapes = [((SIZE + 2 ** l - 1) // 2 ** l,) * 2 for l in (3, 4, 5, 6, 7)]
+        logits = torch.logit(cls.detach().double()).float().contiguous()
+
+        def to_levels(flat, last):
+            res, at = [], 0
+            for (h, w) in shapes:
+                k = h * w * 9
+                res.append(flat[:, at:at + k].reshape(BATCH, h, w, 9 * last).permute(0, 3, 1, 2).contiguous())
+                at += k
+            return res
+        lg_bufs = F.focal_loss_fwd_bwd(logits, reg.detach(), anchors, ann, from_logits=True)
+        lg_mean, _ = event_train(lambda: F.focal_loss_fwd_bwd(
+            logits, reg.detach(), anchors, ann, stages=_lib.STAGE_STREAM, out=lg_bufs, from_logits=True), 20, 5)
+        cls_lv, reg_lv = to_levels(logits, CLASSES), to_levels(reg.detach(), 4)
+        lv_bufs = F.focal_loss_levels_fwd_bwd(cls_lv, reg_lv, anchors, ann, from_logits=True)
+        lv_mean, _ = event_train(lambda: F.focal_loss_levels_fwd_bwd(
+            cls_lv, reg_lv, anchors, ann, stages=_lib.STAGE_STREAM, out=lv_bufs, from_logits=True), 20, 5)
+        del lg_bufs, lv_bufs, cls_lv, reg_lv, logits
+
     # ---- decode + NMS (second half of the metric) ------------------------------------------
     icls_np, ireg_np = synth_infer(np.random.default_rng(3000), BATCH, n, CLASSES)
     icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
@@ -359,7 +380,9 @@ def main():
                      "timing": "HIP events around trains of 20 back-to-back launches, 10 trains",
                      "single_launch_event_pair_ms_mean": k1_mean,
                      "single_launch_event_pair_ms_min": k1_min},
-        "kernels_ms": {"assign_stage": a_mean, "stream_stage": k_mean, "fused_call": f_mean},
+        "kernels_ms": {"assign_stage": a_mean, "stream_stage": k_mean, "fused_call": f_mean,
+                       "stream_stage_from_logits": lg_mean,
+                       "stream_stage_head_layout_from_logits": lv_mean},
         "decode_nms": {"images_per_s": BATCH / (piped_ms * 1e-3), "ms_per_batch": piped_ms,
                        "launch": f"{n_streams} batches in flight on {n_streams} HIP streams",
                        "frac_of_hbm_peak": decode_bytes / (piped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -425,6 +425,8 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const int j0 = row0 / N;
     const int split = (j0 + 1) * N - row0;            // first tile-local row of image j0+1
     const bool two = split < rows;
+    // the tile's codes and the positive counts go out together: one memory latency, not two
+    const int my_code_raw = code[min(row0 + tid, total_rows - 1)];
     // positives of the tile's image(s): sum of the assignment kernel's per-block counts
     int v0 = 0, v1 = 0;
     for (int i = tid; i < nblk; i += kThreads) {
@@ -439,8 +441,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
       s_np[tid >> 6][0] = v0;
       s_np[tid >> 6][1] = v1;
     }
-    int my_code = kCodeNeg;
-    if (tid < rows) my_code = code[row0 + tid];
+    const int my_code = tid < rows ? my_code_raw : kCodeNeg;
     if (tid < kTileRows) s_code[tid] = tid < rows ? my_code : kCodeIgn;
     // any positive or ignored row in this tile?  (also the barrier that publishes s_code, s_np)
     const int special = __syncthreads_or(my_code != kCodeNeg);

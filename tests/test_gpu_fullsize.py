@@ -1,4 +1,4 @@
-"""Full-size runs of the BASELINE.json configurations on the GPU.
+"""Full-size runs of the benchmark configurations on the GPU.
 
 The oracle is too slow for whole batches at these sizes, so each configuration is checked
 (a) against the oracle on a slice it finishes in seconds and (b) through size-independent
@@ -18,7 +18,7 @@ RTOL = 1e-5
 
 # (name, batch, image size, classes, padded GT rows, valid GT rows per image)
 CONFIGS = {
-    "coco608": (16, 608, 80, 20, None),        # BASELINE configs[1] / bench workload
+    "coco608": (16, 608, 80, 20, None),        # the bench.py workload
     "oid800": (8, 800, 601, 8, 8),             # configs[2]: 601-class head, rows of 2404 bytes
     "dense1024": (4, 1024, 80, 256, 256),      # configs[3]: 256 GT boxes per image
 }
