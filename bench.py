@@ -166,7 +166,8 @@ def main():
     ann = torch.from_numpy(ann_np).to(dev)
 
     # Each rank's losses and gradients are scaled by 1/B_global inside the kernels
-    # (batch_divisor); the only exchange is the all-reduce of the 2-float loss vector.
+    # (batch_divisor); the only exchange is the all-reduce of a 4-float vector (loss sums,
+    # positive anchors, images).
     loss_mod = rh.FocalLoss(batch_divisor=BATCH * world)
 
     def local_step():
@@ -175,6 +176,13 @@ def main():
         out = loss_mod(cls, reg, anchors, ann)
         loss = sum(l for l in out.values())      # train.py:185
         loss.backward()                          # train.py:190
+        if world > 1:
+            # what the ranks exchange: loss sums, positive anchors, images (one 16-byte all-reduce)
+            out = dict(out)
+            out["exchange"] = torch.cat([
+                out["classification_loss"].detach(), out["regression_loss"].detach(),
+                loss_mod.last["num_pos"].sum().float().reshape(1),
+                torch.full((1,), float(BATCH), device=dev)])
         return out
 
     # The step is a handful of kernels (~150 us of GPU work), which eager PyTorch cannot
@@ -213,7 +221,7 @@ def main():
         else:
             out = local_step()
         if world > 1:
-            vec = torch.cat([out["classification_loss"].detach(), out["regression_loss"].detach()])
+            vec = out["exchange"].clone()        # the replay rewrites its own copy every step
             if backend == "nccl":
                 pending.append((vec, dist.all_reduce(vec, op=dist.ReduceOp.SUM, async_op=True)))
                 if len(pending) > 4:             # bounded backlog; values are the global losses

@@ -4,8 +4,9 @@ Every quantity of the loss is per image (models/retinanet/losses.py:43-136); the
 only cross-image step is the batch mean (losses.py:139-140).  So a rank runs the
 fused kernels on its own images with ``batch_divisor`` = global batch size, which
 already scales its losses and gradients by 1/B_global, and ONE all-reduce (sum) of
-a 2-float vector over RCCL/xGMI yields the global losses.  Gradients with respect
-to the predictions need no exchange.  The reference's own multi-GPU mechanism is
+a 4-float vector (classification loss, regression loss, number of positive anchors,
+number of images) over RCCL/xGMI yields the global losses and the global counts.
+Gradients with respect to the predictions need no exchange.  The reference's own multi-GPU mechanism is
 nn.DataParallel (train.py:137).
 """
 from __future__ import annotations
@@ -24,8 +25,9 @@ def shard_bounds(global_batch, rank, world_size):
 
 
 def all_reduce_losses(local_losses, group=None):
-    """Sums the [2] loss vectors of all ranks.  The value is the global loss, the
-    gradient is that of the local share (each rank back-propagates its own images)."""
+    """Sums the loss vectors (any length; entries without grad are plain sums) of all ranks.
+    The value is the global sum, the gradient is that of the local share (each rank
+    back-propagates its own images)."""
     if not (dist_.is_available() and dist_.is_initialized()) or dist_.get_world_size(group) == 1:
         return local_losses
     total = local_losses.detach().clone()
@@ -48,6 +50,14 @@ class DataParallelFocalLoss(torch.nn.Module):
 
     def forward(self, classifications, regressions, anchors, annotations):
         out = self.loss_fn(classifications, regressions, anchors, annotations)
-        vec = torch.cat([out["classification_loss"].reshape(1), out["regression_loss"].reshape(1)])
-        vec = all_reduce_losses(vec, self.group)
+        cls_l, reg_l = out["classification_loss"].reshape(1), out["regression_loss"].reshape(1)
+        last = getattr(self.loss_fn, "last", None)
+        if last is not None and "num_pos" in last:
+            counts = torch.stack([last["num_pos"].sum().to(cls_l.dtype),
+                                  cls_l.new_tensor(float(last["num_pos"].numel()))])
+        else:
+            counts = cls_l.new_zeros(2)
+        vec = all_reduce_losses(torch.cat([cls_l, reg_l, counts]), self.group)
+        # global counts of the step, device tensors: positive anchors and images over all ranks
+        self.last_global = {"num_pos": vec[2].detach(), "images": vec[3].detach()}
         return {"classification_loss": vec[0:1], "regression_loss": vec[1:2]}
