@@ -199,3 +199,48 @@ def test_nms_properties_large(rh):
     higher = scores[keep][None, :] >= scores[d_idx][:, None]
     assert bool((over & higher).any(dim=1).all())
     assert np.array_equal(keep.cpu().numpy(), O.nms(boxes.cpu().numpy(), scores.cpu().numpy(), 0.5))
+
+
+def to_levels(flat, size, last, a=9):
+    """[B, N, last] -> per-level [B, A*last, H, W] (inverse of the reference's permute / view / cat,
+    model.py:152-154,196-202,311-313)."""
+    out, at = [], 0
+    for l in (3, 4, 5, 6, 7):
+        h = w = (size + 2 ** l - 1) // 2 ** l
+        k = h * w * a
+        out.append(flat[:, at:at + k].reshape(flat.shape[0], h, w, a * last).permute(0, 3, 1, 2).contiguous())
+        at += k
+    assert at == flat.shape[1]
+    return out
+
+
+@pytest.mark.parametrize("name,from_logits", [("coco608", False), ("coco608", True), ("oid800", True)])
+def test_head_layout_loss_full_size(rh, name, from_logits):
+    """Loss on the per-level head tensors at full size: gradients bit-identical to the flat path."""
+    F = rh.functional
+    cls, reg, anchors, ann, _ = make_inputs(rh, name)
+    size = CONFIGS[name][1]
+    if from_logits:
+        cls = torch.logit(cls.double()).float()
+    flat = F.focal_loss_fwd_bwd(cls, reg, anchors, ann, from_logits=from_logits)
+    c = cls.shape[2]
+    lv = F.focal_loss_levels_fwd_bwd(to_levels(cls, size, c), to_levels(reg, size, 4), anchors, ann,
+                                     from_logits=from_logits)
+    assert torch.equal(lv["num_pos"], flat["num_pos"])
+    assert np.allclose(lv["losses"].cpu().numpy(), flat["losses"].cpu().numpy(), rtol=1e-6)
+    assert np.allclose(lv["per_image"].cpu().numpy(), flat["per_image"].cpu().numpy(), rtol=1e-6)
+    for got, want in zip(lv["d_cls_levels"], to_levels(flat["d_classifications"], size, c)):
+        assert torch.equal(got, want)
+    for got, want in zip(lv["d_reg_levels"], to_levels(flat["d_regressions"], size, 4)):
+        assert torch.equal(got, want)
+
+
+def test_head_layout_postprocess_full_size(rh):
+    size, c, bsz = 608, 80, 16
+    cls, reg, anchors = infer_inputs(rh, bsz, size, c)
+    flat = rh.postprocess(cls, reg, anchors, (size, size))
+    lv = rh.postprocess(to_levels(cls, size, c), to_levels(reg, size, 4), anchors, (size, size))
+    for a, b in zip(lv, flat):
+        assert a["scores"].numel() > 0
+        for k in ("scores", "labels", "boxes"):
+            assert torch.equal(a[k], b[k])
