@@ -203,6 +203,17 @@ int rh_generic_focal_fwd_bwd(const float* inputs, const float* targets, int64_t 
                              size_t workspace_bytes, rh_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Annotation collation on the device  -  the padding step of collater,
+ * models/retinanet/model.py:43-55: out[b, m, :] = (box, label) of image b's m-th annotation
+ * for m < count_b, five -1 otherwise.
+ *   boxes device [T,4], labels device f32 [T] (all images back to back; either may be NULL when
+ *   T == 0), offsets device i32 [B+1] (prefix sums of the counts, offsets[0] = 0),
+ *   out device [B, m, 5] with m >= max count and m >= 1.
+ * ------------------------------------------------------------------------- */
+int rh_collate_annotations_f32(const float* boxes, const float* labels, const int32_t* offsets,
+                               int32_t batch, int32_t m, float* out, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Box decode and clip  -  replace BBoxTransform.forward (utils.py:96-120) and
  * ClipBoxes.forward (utils.py:133-142).
  *   boxes device [N,4] (broadcast over the batch), deltas device [B,N,4],

@@ -459,3 +459,21 @@ def postprocess_image(classification, regression, anchors, height, width,
         keep = keep[:max_det]
     sel = cand[keep]
     return score[sel], label[sel], boxes[sel]
+
+
+# --------------------------------------------------------------------------
+# Annotation collation  (reference: models/retinanet/model.py:27, 43-55)
+# --------------------------------------------------------------------------
+def collate_annotations(targets):
+    """[B, M, 5] float32: image b's rows (x1, y1, x2, y2, label), padded with -1 to the largest
+    count (one row when every image is empty, model.py:55).  ``targets``: list of
+    (boxes [m,4], labels [m]) pairs.  The reference function itself cannot run (it returns an
+    undefined name, model.py:66), so this restatement is unpinned; it is a plain copy loop."""
+    m = max([len(b) for b, _ in targets] + [1])
+    out = -np.ones((len(targets), m, 5), F32)
+    for i, (b, l) in enumerate(targets):
+        k = len(b)
+        if k:
+            out[i, :k, :4] = np.asarray(b, F32).reshape(k, 4)
+            out[i, :k, 4] = np.asarray(l, F32).reshape(k)
+    return out

@@ -80,7 +80,7 @@ inline uint32_t div_magic(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1)
 
 // float32 sigmoid of a head logit (models/retinanet/model.py:177, 193), shared by the loss
 // stream and the score scan so that both see the same probability for the same logit.
-// exp is the hardware exp2 (1 ulp; the rounding of x * log2(e) adds |x| * 4e-8 relative) and
+// exp is the hardware exp2 (1 ulp; the rounding of x * log2(e) adds up to |x| * 6e-8 relative) and
 // the division is the hardware reciprocal plus one Newton step.  The step matters: 1 - p is
 // exact given p, so for p close to 1 the last bit of p decides several digits of a loss
 // gradient, and a plain 1-ulp reciprocal would show there.  exp2 is capped so that 1 + e

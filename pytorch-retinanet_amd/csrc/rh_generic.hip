@@ -59,6 +59,28 @@ __global__ __launch_bounds__(64) void generic_focal_mean_kernel(const double* __
   if (threadIdx.x == 0) *loss_mean = (float)(acc / (double)count);
 }
 
+// Pads per-image annotation lists to the [B, M, 5] layout the loss reads: row m of image b is
+// (x1, y1, x2, y2, label) of its m-th annotation, or five -1 beyond the image's count
+// (models/retinanet/model.py:43-55).  boxes [T,4] and labels [T] hold all images' annotations
+// back to back; offsets [B+1] are the prefix sums of the counts.
+__global__ __launch_bounds__(kThreads) void collate_annotations_kernel(
+    const float* __restrict__ boxes, const float* __restrict__ labels,
+    const int* __restrict__ offsets, float* __restrict__ out, int B, int M) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;   // one output row
+  if (i >= (long long)B * M) return;
+  const int b = (int)(i / M), m = (int)(i - (long long)b * M);
+  const int lo = offsets[b], count = offsets[b + 1] - lo;
+  float r[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+  if (m < count) {
+    const size_t t = (size_t)lo + m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = boxes[t * 4 + k];
+    r[4] = labels[t];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) out[i * 5 + k] = r[k];
+}
+
 }  // namespace rh
 
 using namespace rh;
@@ -92,6 +114,17 @@ int rh_generic_focal_fwd_bwd(const float* inputs, const float* targets, int64_t 
                        (long long)count, loss_mean);
     RH_CHECK_LAUNCH("generic_focal_mean_kernel");
   }
+  return RH_OK;
+}
+
+int rh_collate_annotations_f32(const float* boxes, const float* labels, const int32_t* offsets,
+                               int32_t batch, int32_t m, float* out, rh_stream_t stream) {
+  RH_REQUIRE(batch >= 1 && m >= 1, RH_ESHAPE, "bad shape batch=%d m=%d", batch, m);
+  RH_REQUIRE(offsets && out, RH_EINVAL, "null pointer");
+  const long long rows = (long long)batch * m;
+  hipLaunchKernelGGL(collate_annotations_kernel, dim3((unsigned)((rows + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, (hipStream_t)stream, boxes, labels, offsets, out, batch, m);
+  RH_CHECK_LAUNCH("collate_annotations_kernel");
   return RH_OK;
 }
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "rh_bbox_transform_f32": (C.c_int, [_P, _P, _I32, _I64, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "rh_clip_boxes_f32": (C.c_int, [_P, _I64, _F, _F, _P]),
     "rh_sigmoid_f32": (C.c_int, [_P, _P, _I64, _P]),
+    "rh_collate_annotations_f32": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "rh_nms_workspace_bytes": (_SZ, [_I64]),
     "rh_nms": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
     "rh_postprocess_workspace_bytes": (_SZ, [_I32, _I64, _I32, C.POINTER(PostParams)]),

@@ -375,6 +375,35 @@ def sigmoid(logits):
     return out
 
 
+def collate_annotations(targets, min_rows=1):
+    """Pads per-image targets to the ``[B, M, 5]`` annotation tensor the loss reads (rows
+    ``x1, y1, x2, y2, label``, padding rows all -1), on the device; replaces the annotation half
+    of ``collater`` (models/retinanet/model.py:27,43-55).  ``targets`` is a list of dicts with
+    device tensors ``'boxes'`` [m,4] and ``'labels'`` [m] or [m,1]; M is the largest m (at least
+    ``min_rows``: the reference pads an all-empty batch to one row).  No host read of device data."""
+    if not targets:
+        raise RetinaHeadError("collate_annotations needs at least one image")
+    boxes = [t["boxes"].reshape(-1, 4) for t in targets]
+    labels = [t["labels"].reshape(-1) for t in targets]
+    dev = _dev_check(*boxes, *labels)
+    counts = [int(b.shape[0]) for b in boxes]
+    if any(int(l.shape[0]) != c for l, c in zip(labels, counts)):
+        raise RetinaHeadError("boxes and labels disagree in length")
+    m = max(max(counts), int(min_rows), 1)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    all_boxes = _f32c(torch.cat(boxes)) if offs[-1] else None
+    all_labels = _f32c(torch.cat(labels)) if offs[-1] else None
+    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    out = torch.empty((len(targets), m, 5), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_collate_annotations_f32(
+            _p(all_boxes), _p(all_labels), _p(offsets), len(targets), m, _p(out), _stream(dev)),
+            "rh_collate_annotations_f32")
+    return out
+
+
 def clip_boxes_(boxes, height, width):
     """In place (utils.py:136-140)."""
     dev = _dev_check(boxes)

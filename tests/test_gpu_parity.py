@@ -307,6 +307,21 @@ def test_generic_focal_golden(rh):
                                atol=1e-6 if not reduce else 1e-8), key
 
 
+def test_collate_annotations(rh):
+    rng = np.random.default_rng(4)
+    counts = [3, 0, 7, 1]
+    tg = [(rng.uniform(0, 100, (k, 4)).astype(np.float32), rng.integers(0, 9, k).astype(np.float32))
+          for k in counts]
+    got = rh.collate_annotations([{"boxes": dev(b), "labels": dev(l).reshape(-1, 1)} for b, l in tg])
+    assert got.shape == (4, 7, 5) and np.array_equal(got.cpu().numpy(), O.collate_annotations(tg))
+    empty = [(np.zeros((0, 4), np.float32), np.zeros(0, np.float32))] * 2
+    got = rh.collate_annotations([{"boxes": dev(b), "labels": dev(l)} for b, l in empty])
+    assert got.shape == (2, 1, 5) and np.array_equal(got.cpu().numpy(), O.collate_annotations(empty))
+    # int64 labels, as datasets produce them, and the result feeds the loss as is
+    tg64 = [{"boxes": dev(b), "labels": dev(l.astype(np.int64))} for b, l in tg]
+    assert np.array_equal(rh.collate_annotations(tg64).cpu().numpy(), O.collate_annotations(tg))
+
+
 # ------------------------------------------------------------------ decode / clip
 def test_decode_clip_golden(rh):
     g = load_golden("decode.npz")
