@@ -203,6 +203,18 @@ int rh_generic_focal_fwd_bwd(const float* inputs, const float* targets, int64_t 
                              size_t workspace_bytes, rh_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Detection-to-annotation matching for evaluation  -  the inner loop of evaluate,
+ * csv_eval.py:188-208, with compute_overlap (csv_eval.py:11-35) in float64.
+ *   det_boxes device f32 [B,D,4] and det_labels device i64 [B,D]: each image's detections in
+ *   descending score order (the order rh_postprocess writes); det_count device i32 [B];
+ *   annotations device f32 [B,M,5] (label -1 rows are padding);
+ *   tp device u8 [B,D]: 1 = true positive, 0 = false positive (0 beyond det_count).
+ * ------------------------------------------------------------------------- */
+int rh_match_detections(const float* det_boxes, const int64_t* det_labels, const int32_t* det_count,
+                        const float* annotations, int32_t batch, int32_t d, int32_t m,
+                        double iou_threshold, uint8_t* tp, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Annotation collation on the device  -  the padding step of collater,
  * models/retinanet/model.py:43-55: out[b, m, :] = (box, label) of image b's m-th annotation
  * for m < count_b, five -1 otherwise.

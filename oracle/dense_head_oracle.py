@@ -477,3 +477,95 @@ def collate_annotations(targets):
             out[i, :k, :4] = np.asarray(b, F32).reshape(k, 4)
             out[i, :k, 4] = np.asarray(l, F32).reshape(k)
     return out
+
+
+# --------------------------------------------------------------------------
+# Detection evaluation  (reference: csv_eval.py:11-35, 38-62, 97-118, 176-230)
+# --------------------------------------------------------------------------
+def compute_overlap(a, b):
+    """[N,K] float64 IoU, csv_eval.py:11-35 (union clamped at the float64 epsilon)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    iw = np.minimum(a[:, 2:3], b[:, 2]) - np.maximum(a[:, 0:1], b[:, 0])
+    ih = np.minimum(a[:, 3:4], b[:, 3]) - np.maximum(a[:, 1:2], b[:, 1])
+    iw = np.maximum(iw, 0)
+    ih = np.maximum(ih, 0)
+    ua = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + area - iw * ih
+    ua = np.maximum(ua, np.finfo(float).eps)
+    return iw * ih / ua
+
+
+def match_detections(det_boxes, det_labels, annotations, iou_threshold=0.5):
+    """One image.  ``det_boxes`` [D,4] / ``det_labels`` [D] in descending score order,
+    ``annotations`` [M,5] (label -1 rows are padding).  Returns uint8 [D]: 1 where the detection
+    is a true positive, i.e. its best-overlapping annotation of the same class (first on ties)
+    reaches the threshold and has not been claimed by an earlier detection (csv_eval.py:188-208).
+    All arithmetic in float64 like the reference's numpy code."""
+    det_boxes = np.asarray(det_boxes, np.float64).reshape(-1, 4)
+    ann = np.asarray(annotations, np.float64).reshape(-1, 5)
+    ann = ann[ann[:, 4] != -1]
+    tp = np.zeros(det_boxes.shape[0], np.uint8)
+    taken = np.zeros(ann.shape[0], bool)
+    for d in range(det_boxes.shape[0]):
+        same = np.nonzero(ann[:, 4] == det_labels[d])[0]
+        if same.size == 0:
+            continue
+        ov = compute_overlap(det_boxes[d:d + 1], ann[same, :4])[0]
+        k = int(np.argmax(ov))
+        if ov[k] >= iou_threshold and not taken[same[k]]:
+            tp[d] = 1
+            taken[same[k]] = True
+    return tp
+
+
+def average_precision(recall, precision):
+    """csv_eval.py:38-62: area under the precision envelope."""
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([0.0], precision, [0.0]))
+    for i in range(mpre.size - 1, 0, -1):
+        mpre[i - 1] = max(mpre[i - 1], mpre[i])
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    return float(np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1]))
+
+
+def average_precisions(scores, labels, tp, annotations, num_classes):
+    """Dataset-level AP per class from per-image lists (csv_eval.py:176-230).
+    ``scores`` / ``labels`` / ``tp``: lists with one array per image (detections in the order
+    they were matched); ``annotations``: list of [M,5].  Returns (ap [C], num_annotations [C])."""
+    ap = np.zeros(num_classes, np.float64)
+    num = np.zeros(num_classes, np.float64)
+    for c in range(num_classes):
+        s = np.concatenate([np.asarray(sc, np.float64)[np.asarray(lb) == c] for sc, lb in zip(scores, labels)] + [np.zeros(0)])
+        t = np.concatenate([np.asarray(x, np.float64)[np.asarray(lb) == c] for x, lb in zip(tp, labels)] + [np.zeros(0)])
+        num[c] = sum(int((np.asarray(a)[:, 4] == c).sum()) for a in annotations)
+        if num[c] == 0:
+            continue                                  # csv_eval.py:211-213: AP 0
+        order = np.argsort(-s, kind="stable")
+        tps = np.cumsum(t[order])
+        fps = np.cumsum(1.0 - t[order])
+        recall = tps / num[c]
+        precision = tps / np.maximum(tps + fps, np.finfo(np.float64).eps)
+        ap[c] = average_precision(recall, precision)
+    return ap, num
+
+
+def evaluate_detections(det_boxes, det_scores, det_labels, det_counts, annotations, scales,
+                        num_classes, iou_threshold=0.5, score_threshold=0.05, max_detections=100):
+    """The whole of csv_eval.evaluate on padded arrays: boxes /= scale in float32, score filter,
+    descending sort, truncation (csv_eval.py:95-110), matching, AP."""
+    sc_l, lb_l, tp_l, an_l = [], [], [], []
+    for i in range(len(det_counts)):
+        d = int(det_counts[i])
+        boxes = (np.asarray(det_boxes[i][:d], np.float32) / np.float32(scales[i])).astype(np.float32)
+        scores = np.asarray(det_scores[i][:d], np.float32)
+        labels = np.asarray(det_labels[i][:d])
+        idx = np.where(scores > score_threshold)[0]
+        order = idx[np.argsort(-scores[idx], kind="stable")][:max_detections]
+        ann = np.asarray(annotations[i], np.float64)
+        ann = ann[ann[:, 4] != -1]
+        sc_l.append(scores[order])
+        lb_l.append(labels[order])
+        tp_l.append(match_detections(boxes[order], labels[order], ann, iou_threshold))
+        an_l.append(ann)
+    return average_precisions(sc_l, lb_l, tp_l, an_l, num_classes)

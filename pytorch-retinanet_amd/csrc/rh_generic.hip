@@ -81,6 +81,67 @@ __global__ __launch_bounds__(kThreads) void collate_annotations_kernel(
   for (int k = 0; k < 5; ++k) out[i * 5 + k] = r[k];
 }
 
+// Greedy matching of one image's detections to its annotations for detection evaluation
+// (csv_eval.py:188-208).  Detections come in descending score order; a detection is a true
+// positive when its best-overlapping annotation of the same class (first on ties) reaches the
+// IoU threshold and no earlier detection has claimed it.  IoU in float64 with the operation
+// order of csv_eval.compute_overlap (csv_eval.py:21-35).  One wave per image: lanes share the
+// annotations, detections are walked in order.
+__global__ __launch_bounds__(64) void match_detections_kernel(
+    const float4* __restrict__ det_boxes, const long long* __restrict__ det_labels,
+    const int* __restrict__ det_count, const float* __restrict__ ann, unsigned char* __restrict__ tp,
+    int D, int M, double thresh) {
+  extern __shared__ unsigned char s_taken[];
+  const int j = blockIdx.x, lane = threadIdx.x;
+  for (int m = lane; m < M; m += 64) s_taken[m] = 0;
+  __syncthreads();
+  const float* aj = ann + (size_t)j * M * 5;
+  const int count = min(det_count[j], D);
+  for (int d = 0; d < D; ++d) {
+    unsigned char flag = 0;
+    if (d < count) {
+      const float4 bf = det_boxes[(size_t)j * D + d];
+      const double x1 = bf.x, y1 = bf.y, x2 = bf.z, y2 = bf.w;
+      const double lab = (double)det_labels[(size_t)j * D + d];
+      const double area_d = (x2 - x1) * (y2 - y1);
+      double best = -1.0;
+      int best_m = M;
+      for (int m = lane; m < M; m += 64) {
+        const double al = aj[m * 5 + 4];
+        if (al == -1.0 || al != lab) continue;
+        const double ax1 = aj[m * 5 + 0], ay1 = aj[m * 5 + 1], ax2 = aj[m * 5 + 2], ay2 = aj[m * 5 + 3];
+        const double area = (ax2 - ax1) * (ay2 - ay1);
+        double iw = fmin(x2, ax2) - fmax(x1, ax1);
+        double ih = fmin(y2, ay2) - fmax(y1, ay1);
+        iw = fmax(iw, 0.0);
+        ih = fmax(ih, 0.0);
+        double ua = area_d + area - iw * ih;
+        ua = fmax(ua, 2.220446049250313e-16);
+        const double iou = iw * ih / ua;
+        if (iou > best) {
+          best = iou;
+          best_m = m;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int om = __shfl_xor(best_m, o, 64);
+        if (ob > best || (ob == best && om < best_m)) {
+          best = ob;
+          best_m = om;
+        }
+      }
+      if (best_m < M && best >= thresh && !s_taken[best_m]) {
+        flag = 1;
+        if (lane == 0) s_taken[best_m] = 1;
+      }
+      __syncthreads();   // the claim is visible before the next detection looks
+    }
+    if (lane == 0) tp[(size_t)j * D + d] = flag;
+  }
+}
+
 }  // namespace rh
 
 using namespace rh;
@@ -125,6 +186,27 @@ int rh_collate_annotations_f32(const float* boxes, const float* labels, const in
   hipLaunchKernelGGL(collate_annotations_kernel, dim3((unsigned)((rows + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, (hipStream_t)stream, boxes, labels, offsets, out, batch, m);
   RH_CHECK_LAUNCH("collate_annotations_kernel");
+  return RH_OK;
+}
+
+int rh_match_detections(const float* det_boxes, const int64_t* det_labels, const int32_t* det_count,
+                        const float* annotations, int32_t batch, int32_t d, int32_t m,
+                        double iou_threshold, uint8_t* tp, rh_stream_t stream) {
+  RH_REQUIRE(batch >= 1 && d >= 0 && m >= 0, RH_ESHAPE, "bad shape batch=%d d=%d m=%d", batch, d, m);
+  if (d == 0) return RH_OK;
+  RH_REQUIRE(det_boxes && det_labels && det_count && tp && (annotations || m == 0), RH_EINVAL,
+             "null pointer");
+  RH_REQUIRE(aligned16(det_boxes), RH_EALIGN, "det_boxes must be 16-byte aligned");
+  RH_REQUIRE(m <= 64 * 1024, RH_ESHAPE, "m=%d: at most 65536 annotation rows per image", m);
+  const size_t lds = (size_t)(m > 0 ? m : 1);
+  if (lds > 48 * 1024)
+    RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(match_detections_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(match_detections_kernel, dim3(batch), dim3(64), lds, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(det_boxes),
+                     reinterpret_cast<const long long*>(det_labels), det_count, annotations, tp, d, m,
+                     iou_threshold);
+  RH_CHECK_LAUNCH("match_detections_kernel");
   return RH_OK;
 }
 

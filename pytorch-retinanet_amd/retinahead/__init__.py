@@ -7,9 +7,10 @@ from ._lib import LIB_PATH, RetinaHeadError, load as load_library
 from .modules import (Anchors, BBoxTransform, ClipBoxes, FocalLoss, GenericFocalLoss, batched_nms,
                       calc_iou, nms, postprocess)
 from .functional import collate_annotations, sigmoid
+from .evaluate import DetectionEvaluator
 from . import functional
 from . import dist
 
 __all__ = ["Anchors", "BBoxTransform", "ClipBoxes", "FocalLoss", "GenericFocalLoss", "batched_nms",
-           "calc_iou", "nms", "postprocess", "sigmoid", "collate_annotations", "functional", "dist", "load_library", "LIB_PATH",
+           "calc_iou", "nms", "postprocess", "sigmoid", "collate_annotations", "DetectionEvaluator", "functional", "dist", "load_library", "LIB_PATH",
            "RetinaHeadError"]

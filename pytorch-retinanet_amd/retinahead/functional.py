@@ -404,6 +404,26 @@ def collate_annotations(targets, min_rows=1):
     return out
 
 
+def match_detections(det_boxes, det_labels, det_count, annotations, iou_threshold=0.5):
+    """uint8 [B,D]: 1 where a detection is a true positive (csv_eval.py:188-208).  ``det_boxes``
+    [B,D,4] / ``det_labels`` [B,D] hold each image's detections in descending score order,
+    ``det_count`` [B] how many are valid, ``annotations`` [B,M,5] the padded ground truth."""
+    dev = _dev_check(det_boxes, det_labels, det_count, annotations)
+    boxes, ann = _f32c(det_boxes), _f32c(annotations)
+    labels = det_labels.to(torch.int64).contiguous()
+    count = det_count.to(torch.int32).contiguous()
+    if boxes.dim() != 3 or boxes.shape[2] != 4 or tuple(labels.shape) != tuple(boxes.shape[:2]) \
+            or ann.dim() != 3 or ann.shape[2] != 5 or ann.shape[0] != boxes.shape[0]:
+        raise RetinaHeadError("expected det_boxes [B,D,4], det_labels [B,D], annotations [B,M,5]")
+    bsz, d = boxes.shape[:2]
+    tp = torch.zeros((bsz, d), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rh_match_detections(_p(boxes), _p(labels), _p(count), _p(ann), bsz, d,
+                                                   ann.shape[1], float(iou_threshold), _p(tp),
+                                                   _stream(dev)), "rh_match_detections")
+    return tp
+
+
 def clip_boxes_(boxes, height, width):
     """In place (utils.py:136-140)."""
     dev = _dev_check(boxes)

@@ -322,6 +322,44 @@ def test_collate_annotations(rh):
     assert np.array_equal(rh.collate_annotations(tg64).cpu().numpy(), O.collate_annotations(tg))
 
 
+def test_detection_matching_and_ap_golden(rh):
+    """Device matching + host AP against csv_eval.evaluate's results (tests/golden/evaluate.npz)
+    and, flag by flag, against the oracle."""
+    g = load_golden("evaluate.npz")
+    n_img = len(g["det_counts"])
+    ann = dev(g["annotations"])
+    for tag, thr in (("t50", 0.5), ("t75", 0.75)):
+        ev = rh.DetectionEvaluator(5, iou_threshold=thr, max_detections=25)
+        results = []
+        for i in range(n_img):
+            d = int(g["det_counts"][i])
+            results.append({"boxes": dev(g["det_boxes"][i, :d]), "labels": dev(g["det_labels"][i, :d]),
+                            "scores": dev(g["det_scores"][i, :d])})
+        ev.update(results[:3], ann[:3], scales=g["scales"][:3])          # two batches
+        ev.update(results[3:], ann[3:], scales=g["scales"][3:])
+        aps = ev.average_precisions()
+        assert np.allclose([aps[c][0] for c in range(5)], g[tag + ".ap"], rtol=1e-12, atol=0)
+        assert np.array_equal([aps[c][1] for c in range(5)], g[tag + ".num_annotations"])
+    # flags against the oracle on random, dense cases (many detections per annotation, ties)
+    rng = np.random.default_rng(8)
+    bsz, d, m = 5, 300, 70
+    a = -np.ones((bsz, m, 5), np.float32)
+    for j in range(bsz):
+        k = int(rng.integers(0, m + 1)) if j else m
+        xy = rng.integers(0, 200, (k, 2))
+        a[j, :k, :2], a[j, :k, 2:4], a[j, :k, 4] = xy, xy + rng.integers(10, 60, (k, 2)), rng.integers(0, 3, k)
+    src = a[np.arange(bsz)[:, None], rng.integers(0, m, (bsz, d))]        # copies of annotation rows
+    boxes = (src[:, :, :4] + rng.integers(-6, 7, (bsz, d, 4))).astype(np.float32)
+    boxes[:, ::7] = src[:, ::7, :4]                                        # exact duplicates: IoU ties
+    labels = rng.integers(0, 3, (bsz, d))
+    counts = np.array([d, 0, 17, d, 250], np.int32)
+    tp = rh.functional.match_detections(dev(boxes), dev(labels), dev(counts), dev(a), 0.5).cpu().numpy()
+    for j in range(bsz):
+        k = int(counts[j])
+        assert np.array_equal(tp[j, :k], O.match_detections(boxes[j, :k], labels[j, :k], a[j], 0.5)), j
+        assert not tp[j, k:].any()
+
+
 # ------------------------------------------------------------------ decode / clip
 def test_decode_clip_golden(rh):
     g = load_golden("decode.npz")

@@ -124,3 +124,16 @@ def test_generic_focal():
             loss, grad = O.generic_focal_fwd_bwd(g[key + ".inp"], t, logits=logits, reduce=reduce)
             assert np.allclose(loss, g[key + ".loss"], rtol=2e-5, atol=1e-7), key
             assert np.allclose(grad, g[key + ".grad"], rtol=2e-4, atol=1e-6 if not reduce else 1e-8), key
+
+
+def test_detection_evaluation_matches_reference():
+    """Fixtures: csv_eval.evaluate run on stand-in dataset / network objects that hand it fixed
+    annotations and detections (tools/gen_golden.py), and csv_eval.compute_overlap."""
+    g = load_golden("evaluate.npz")
+    assert np.array_equal(O.compute_overlap(g["overlap.a"], g["overlap.b"]), g["overlap.iou"])
+    for tag, thr in (("t50", 0.5), ("t75", 0.75)):
+        ap, num = O.evaluate_detections(g["det_boxes"], g["det_scores"], g["det_labels"], g["det_counts"],
+                                        g["annotations"], g["scales"], 5, iou_threshold=thr,
+                                        score_threshold=0.05, max_detections=25)
+        assert np.array_equal(num, g[tag + ".num_annotations"])
+        assert np.allclose(ap, g[tag + ".ap"], rtol=1e-12, atol=0), (ap, g[tag + ".ap"])

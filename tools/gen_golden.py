@@ -277,6 +277,93 @@ def main():
             g[key + ".inp"] = inp
     g["targets"] = t
     np.savez_compressed(os.path.join(OUT, "generic_focal.npz"), **g)
+
+    # ---------------- detection evaluation (csv_eval.py:11-35, 149-237) ----------------
+    # evaluate() wants a dataset and a network; both are stand-ins that hand it fixed
+    # annotations and fixed detections, so what is recorded is the reference's own matching
+    # (compute_overlap, greedy assignment per class) and its AP arithmetic.
+    csv_eval = load("ref_csv_eval", "csv_eval.py")
+    rng = np.random.default_rng(303)
+    n_img, n_cls, max_gt, max_det = 7, 5, 6, 40
+    ann = -np.ones((n_img, max_gt, 5), np.float32)
+    gt_counts = [4, 0, 6, 2, 5, 3, 1]
+    for i, k in enumerate(gt_counts):
+        x1, y1 = rng.integers(0, 300, k), rng.integers(0, 300, k)
+        ann[i, :k, 0], ann[i, :k, 1] = x1, y1
+        ann[i, :k, 2], ann[i, :k, 3] = x1 + rng.integers(20, 120, k), y1 + rng.integers(20, 120, k)
+        ann[i, :k, 4] = rng.integers(0, n_cls - 1, k)          # the last class never occurs
+    scales = np.array([1.0, 1.0, 0.5, 1.0, 2.0, 1.0, 1.0], np.float32)
+    det_boxes = np.zeros((n_img, max_det, 4), np.float32)
+    det_scores = np.zeros((n_img, max_det), np.float32)
+    det_labels = np.zeros((n_img, max_det), np.int64)
+    det_counts = np.zeros(n_img, np.int32)
+    for i in range(n_img):
+        k = gt_counts[i]
+        rows = []
+        for j in range(k):                                       # 0-3 jittered copies of each box
+            for _ in range(int(rng.integers(0, 4))):
+                jit = rng.normal(0, rng.choice([2.0, 15.0]), 4)
+                lab = ann[i, j, 4] if rng.random() < 0.8 else rng.integers(0, n_cls)
+                rows.append(np.concatenate([ann[i, j, :4] + jit, [lab]]))
+        for _ in range(int(rng.integers(0, 8))):                 # clutter
+            x1, y1 = rng.uniform(0, 300, 2)
+            rows.append(np.array([x1, y1, x1 + rng.uniform(10, 100), y1 + rng.uniform(10, 100),
+                                  rng.integers(0, n_cls)]))
+        if i == 5:
+            rows = []                                            # an image without detections
+        rows = rows[:max_det]
+        d = len(rows)
+        det_counts[i] = d
+        if d:
+            r = np.array(rows)
+            sc = np.sort(rng.uniform(0.06, 1.0, d).astype(np.float32))[::-1]   # distinct, descending
+            det_boxes[i, :d] = (r[:, :4] * scales[i]).astype(np.float32)       # network-scale boxes
+            det_scores[i, :d] = sc
+            det_labels[i, :d] = r[:, 4].astype(np.int64)
+
+    class Dataset:
+        def __len__(self):
+            return n_img
+
+        def __getitem__(self, index):
+            self.current = index
+            return {"img": torch.zeros(8, 8, 3), "scale": float(scales[index])}
+
+        def num_classes(self):
+            return n_cls
+
+        def load_annotations(self, index):
+            return ann[index, :gt_counts[index]].astype(np.float64)
+
+        def label_to_name(self, label):
+            return str(label)
+
+    data = Dataset()
+
+    class Net:
+        def eval(self):
+            return self
+
+        def __call__(self, img):
+            i, d = data.current, int(det_counts[data.current])
+            return (torch.from_numpy(det_scores[i, :d].copy()), torch.from_numpy(det_labels[i, :d].copy()),
+                    torch.from_numpy(det_boxes[i, :d].copy()))
+
+    ev = {}
+    for tag, thr in (("t50", 0.5), ("t75", 0.75)):
+        aps = csv_eval.evaluate(data, Net(), iou_threshold=thr, score_threshold=0.05, max_detections=25)
+        ev[tag + ".ap"] = np.array([aps[c][0] for c in range(n_cls)], np.float64)
+        ev[tag + ".num_annotations"] = np.array([aps[c][1] for c in range(n_cls)], np.float64)
+    a = rng.uniform(0, 50, (9, 4))
+    a[:, 2:] += a[:, :2]
+    b = rng.uniform(0, 50, (5, 4))
+    b[:, 2:] += b[:, :2]
+    b[4] = [3, 3, 3, 3]
+    ev["overlap.a"], ev["overlap.b"] = a, b
+    ev["overlap.iou"] = csv_eval.compute_overlap(a, b)
+    ev.update(annotations=ann, scales=scales, det_boxes=det_boxes, det_scores=det_scores,
+              det_labels=det_labels, det_counts=det_counts)
+    np.savez_compressed(os.path.join(OUT, "evaluate.npz"), **ev)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
