@@ -38,3 +38,35 @@ for ns in (1, 2, 3, 4, 6, 8):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t1) / (rounds * ns) * 1e3
     print(f"B={B} streams={ns}: {ms * 1e3:7.1f} us/batch  {B / ms * 1e3:9.0f} img/s")
+
+# host cost of one call (nothing else queued), and the same pipeline replayed from hipGraphs
+t1 = time.perf_counter()
+for _ in range(200):
+    post(outs[0])
+host_us = (time.perf_counter() - t1) / 200 * 1e6
+torch.cuda.synchronize()
+print(f"host time per postprocess_raw call (enqueue only): {host_us:.1f} us")
+for ns in (1, 2, 3, 4, 6):
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    graphs, outs = [], []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st):
+            o = post()
+            post(o)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            post(o)
+        graphs.append(g)
+        outs.append(o)
+    torch.cuda.synchronize()
+    rounds = max(120 // ns, 10)
+    t1 = time.perf_counter()
+    for _ in range(rounds):
+        for st, g in zip(streams, graphs):
+            with torch.cuda.stream(st):
+                g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) / (rounds * ns) * 1e3
+    print(f"B={B} streams={ns} (hipGraph replay): {ms * 1e3:7.1f} us/batch  {B / ms * 1e3:9.0f} img/s")
