@@ -86,6 +86,7 @@ def event_train(fn, launches, reps):
         b.record()
     torch.cuda.synchronize()
     ms = [a.elapsed_time(b) / launches for a, b in pairs]
+    event_train.last = ms
     return float(np.mean(ms)), float(np.min(ms))
 
 
@@ -296,6 +297,7 @@ def main():
             stream_fn()
         k1_mean, k1_min = event_times(stream_fn, 100)
         k_mean, k_min = event_train(stream_fn, 20, 10)
+        k_p10, k_p50, k_p90 = (float(np.percentile(event_train.last, q)) for q in (10, 50, 90))
         assign_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann,
                                                  stages=_lib.STAGE_ASSIGN, out=bufs)
         a_mean, _ = event_times(assign_fn, 50)
@@ -385,6 +387,7 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes": algo_bytes,
                      "kernel_ms_mean": k_mean, "kernel_ms_min": k_min,
+                     "kernel_ms_p10_p50_p90": [k_p10, k_p50, k_p90],
                      "timing": "HIP events around trains of 20 back-to-back launches, 10 trains",
                      "single_launch_event_pair_ms_mean": k1_mean,
                      "single_launch_event_pair_ms_min": k1_min},

@@ -204,11 +204,13 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_data_parallel_equals_single_process():
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_equals_single_process(world):
+    """world ranks (gloo), images sharded (2+1 and 1+1+1 of the fixture's three): every rank sees the
+    single-process losses, and the ranks' gradients concatenate to the single-process gradients."""
     from retinahead import dist as rdist
     assert [rdist.shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [rdist.shard_bounds(16, r, 8) for r in (0, 7)] == [(0, 2), (14, 16)]
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
