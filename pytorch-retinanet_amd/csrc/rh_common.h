@@ -78,6 +78,25 @@ __device__ __forceinline__ int wave_sum(int v) {
 __device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
 inline uint32_t div_magic(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
 
+// min / max / clamp-at-zero as single instructions.  fminf / fmaxf compile to the same
+// instructions wrapped in NaN-quieting moves (v_max x, x, x) on every operand, which in the
+// pair loops of the assignment and NMS-mask kernels more than doubles the instruction count;
+// for the finite box coordinates those loops see, the results are identical.
+__device__ __forceinline__ float vmin(const float a, const float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(const float a, const float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax0(const float a) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
 // float32 sigmoid of a head logit (models/retinanet/model.py:177, 193), shared by the loss
 // stream and the score scan so that both see the same probability for the same logit.
 // exp is the hardware exp2 (1 ulp; the rounding of x * log2(e) adds up to |x| * 6e-8 relative) and

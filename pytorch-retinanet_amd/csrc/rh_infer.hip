@@ -955,21 +955,6 @@ __global__ __launch_bounds__(kThreads) void nms_mask_general_kernel(const float4
 // count.  Each test shifts its result into the lane's word through the carry
 // (word = 2 * word + test), walking the 32 boxes of a half-word from the highest down.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float vmin(const float a, const float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float vmax(const float a, const float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float vmax0(const float a) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
-  return r;
-}
 // word = 2 * word + (a > b)
 __device__ __forceinline__ void shift_in_gt(unsigned& word, const float a, const float b) {
   asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"

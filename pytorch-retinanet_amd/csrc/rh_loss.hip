@@ -63,8 +63,13 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 // blk_pos[image][block]: no atomics and nothing to zero beforehand.
 // Max / first arg-max (losses.py:61), thresholds (:70-72), label lookup (:76-79), count (:74).
 // ---------------------------------------------------------------------------
+// Two anchors per thread.  Four were slower at both ends: with short annotation lists the
+// kernel is bound by its few dependent memory latencies and a coarser grid only unbalances it
+// (15.2 against 13.7 us at 16 x 69 354 anchors), and with 256 rows per image the grid gets too
+// small to hide the LDS and branch latencies of the pair loop (79 against 64 us at 4 x 196 416).
 constexpr int kAssignPer = 2;
 constexpr int kAssignBlock = kThreads * kAssignPer;   // anchors per block
+static inline int assign_blocks(long long n) { return (int)((n + kAssignBlock - 1) / kAssignBlock); }
 
 // Where the packed codes go.  num_levels == 0: code[j*N + n], the order of the flat [B,N,C]
 // tensors.  Otherwise the head-layout kernel's order: within pyramid level l the codes of
@@ -152,20 +157,23 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     __syncthreads();
     if (cnt == 0 && len > 0) lab0 = s_lab[0];
     // ---- scan the chunk's valid boxes
-#pragma unroll 2
+    // The box of the next iteration is read from LDS before the current one is used, so the
+    // LDS latency overlaps the arithmetic instead of opening every iteration.
+    float4 bn = s_box[0];
     for (int i = 0; i < len; ++i) {
-      const float4 b = s_box[i];
+      const float4 b = bn;
+      bn = s_box[min(i + 1, kGtChunk - 1)];
       // overlap test for the thread's anchors first; one (rare) branch per GT box
       float iw[kAssignPer], ih[kAssignPer], mm[kAssignPer];
 #pragma unroll
       for (int k = 0; k < kAssignPer; ++k) {
-        iw[k] = fminf(a[k].z, b.z) - fmaxf(a[k].x, b.x);
-        ih[k] = fminf(a[k].w, b.w) - fmaxf(a[k].y, b.y);
-        mm[k] = fminf(iw[k], ih[k]);
+        iw[k] = vmin(a[k].z, b.z) - vmax(a[k].x, b.x);
+        ih[k] = vmin(a[k].w, b.w) - vmax(a[k].y, b.y);
+        mm[k] = vmin(iw[k], ih[k]);
       }
       float any = mm[0];
 #pragma unroll
-      for (int k = 1; k < kAssignPer; ++k) any = fmaxf(any, mm[k]);
+      for (int k = 1; k < kAssignPer; ++k) any = vmax(any, mm[k]);
       if (any > 0.0f) {
         const float ab = s_area[i];
         const int lb = s_lab[i];
@@ -405,6 +413,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // Requirements checked on the host: 4 <= C < 8192, N >= 64, all pointers 16-byte
 // aligned, B*N < 2^31.
 // ---------------------------------------------------------------------------
+// (Double-buffering the loads of wide rows, which take several batches of U float4 per thread,
+// was measured at C = 601 and changed nothing: 886 against 887 us.)
 template <int U, bool kLogits>
 __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
@@ -526,6 +536,19 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
             const float in[4] = {val[u].x, val[u].y, val[u].z, val[u].w};
             float out[4];
             int cd = s_code[r];
+            // Most float4 of a tile with a few positive or ignored rows still lie in plain
+            // negative rows of one image: those take the cheap element path as well.
+            const int r_end = col + 3 >= C ? r + 1 : r;   // C >= 4: a float4 spans at most two rows
+            const bool second4 = r >= split;
+            if (cd == kCodeNeg && s_code[r_end] == kCodeNeg && (r_end >= split) == second4) {
+              const float k0g = -(1.0f - fc.alpha) * (second4 ? sc1 : sc0);
+              float l = focal_zero_in<kLogits>(in[0], fc, k0l, k0g, out[0]);
+              l += focal_zero_in<kLogits>(in[1], fc, k0l, k0g, out[1]);
+              l += focal_zero_in<kLogits>(in[2], fc, k0l, k0g, out[2]);
+              l += focal_zero_in<kLogits>(in[3], fc, k0l, k0g, out[3]);
+              cl0 += second4 ? 0.f : l;
+              cl1 += second4 ? l : 0.f;
+            } else
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               if (col >= C) {            // C >= 4: at most one row change per float4
@@ -981,7 +1004,7 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   LossWorkspace w;
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = (int)((n + kAssignBlock - 1) / kAssignBlock);
+  w.nblk = assign_blocks(n);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
@@ -1059,7 +1082,7 @@ static LossWorkspace carve_levels(void* ws, int batch, long long n, int m, long 
   LossWorkspace w;
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = (int)((n + kAssignBlock - 1) / kAssignBlock);
+  w.nblk = assign_blocks(n);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)batch * blocks * 2);
@@ -1094,7 +1117,7 @@ static LossWorkspace carve_assign(void* ws, int batch, long long n, int m) {
   LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = (int)((n + kAssignBlock - 1) / kAssignBlock);
+  w.nblk = assign_blocks(n);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.bytes = cv.off;
   return w;
