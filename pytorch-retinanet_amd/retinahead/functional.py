@@ -468,8 +468,11 @@ def nms(boxes, scores, iou_threshold, labels: Optional[torch.Tensor] = None):
 
 def postprocess_raw(classifications, regressions, anchors_t, height, width, score_thresh=0.05,
                     iou_thresh=0.5, per_class=False, pre_nms_topk=0, max_det=0, cand_cap=4096,
-                    stages=_lib.POST_ALL, out=None, from_logits=False):
+                    stages=_lib.POST_ALL, out=None, from_logits=False, ws=None):
     """One pass of the batched post-processing kernels; no host synchronisation.
+    ``out`` carries the output buffers of an earlier call; ``ws`` (a uint8 device tensor of at least
+    ``out["workspace_bytes"]`` bytes) replaces the per-stream cached workspace, which callers
+    need when they run the stages of one batch on different streams.
 
     Returns dict(scores [B,cap], labels [B,cap] i64, boxes [B,cap,4], counts [3,B] i32) where
     counts rows are (kept, candidates over threshold, candidates dropped for lack of room).
@@ -499,7 +502,11 @@ def postprocess_raw(classifications, regressions, anchors_t, height, width, scor
     need = lib.rh_postprocess_workspace_bytes(bsz, n, c, C.byref(params))
     if need == 0:
         raise RetinaHeadError("postprocess: " + _lib.last_error())
-    ws = workspace(dev, need, "post")
+    out["workspace_bytes"] = int(need)
+    if ws is None:
+        ws = workspace(dev, need, "post")
+    elif ws.numel() < need or ws.dtype != torch.uint8 or ws.device != dev:
+        raise RetinaHeadError(f"workspace must be a uint8 tensor of at least {need} bytes on {dev}")
     cnt = out["counts"]
     with torch.cuda.device(dev):
         _lib.check(lib.rh_postprocess(

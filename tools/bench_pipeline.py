@@ -70,3 +70,60 @@ for ns in (1, 2, 3, 4, 6):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t1) / (rounds * ns) * 1e3
     print(f"B={B} streams={ns} (hipGraph replay): {ms * 1e3:7.1f} us/batch  {B / ms * 1e3:9.0f} img/s")
+
+
+# One stream runs the score scans back to back (the HBM-bound stage); the rest of each batch
+# (sort, mask, sweep) follows on one of a few other streams; a ring of buffer sets keeps
+# several batches in flight.
+from retinahead import _lib  # noqa: E402
+for n_tail, ring in ((1, 3), (2, 4), (3, 6), (4, 8)):
+    scan_stream = torch.cuda.Stream(device=dev)
+    tails = [torch.cuda.Stream(device=dev) for _ in range(n_tail)]
+    slots = []
+    for _ in range(ring):
+        o = post()
+        slots.append(dict(out=o, ws=torch.empty(o["workspace_bytes"], dtype=torch.uint8, device=dev),
+                          scanned=torch.cuda.Event(), done=torch.cuda.Event()))
+    torch.cuda.synchronize()
+
+    def run(batches):
+        for b in range(batches):
+            sl = slots[b % ring]
+            with torch.cuda.stream(scan_stream):
+                if b >= ring:
+                    scan_stream.wait_event(sl["done"])          # the slot's previous batch is finished
+                F.postprocess_raw(icls, ireg, anchors, 608, 608, cand_cap=4096, stages=_lib.POST_DECODE,
+                                  out=sl["out"], ws=sl["ws"])
+                sl["scanned"].record(scan_stream)
+            tl = tails[b % n_tail]
+            with torch.cuda.stream(tl):
+                tl.wait_event(sl["scanned"])
+                F.postprocess_raw(icls, ireg, anchors, 608, 608, cand_cap=4096,
+                                  stages=_lib.POST_SORT | _lib.POST_NMS, out=sl["out"], ws=sl["ws"])
+                sl["done"].record(tl)
+    run(2 * ring)
+    torch.cuda.synchronize()
+    nb = 240
+    t1 = time.perf_counter()
+    run(nb)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) / nb * 1e3
+    ref = post()
+    torch.cuda.synchronize()
+    same = True
+    for si, sl in enumerate(slots):
+        for k in ("counts", "scores", "labels", "boxes"):
+            if k == "counts":
+                eq = torch.equal(sl["out"][k], ref[k])
+            else:      # rows beyond an image's count are not written
+                kept = ref["counts"][0]
+                eq = all(torch.equal(sl["out"][k][i, :int(kept[i])], ref[k][i, :int(kept[i])]) for i in range(B))
+            if not eq:
+                same = False
+                print("   slot", si, k, "differs")
+    print(f"B={B} scan stream + {n_tail} tail streams, ring {ring}: {ms * 1e3:7.1f} us/batch  "
+          f"{B / ms * 1e3:9.0f} img/s  results {'identical' if same else 'DIFFER'}")
+
+
+# (Giving the scan stream and the tail streams disjoint shares of the compute units would be the
+# next step, but hipExtStreamCreateWithCUMask fails on this pool: "out of memory".)
