@@ -1,12 +1,13 @@
 // Inference half of the dense-head path on gfx950: box decode / clip, per-anchor
-// class max + score threshold + candidate compaction, per-image sort, bitmask NMS
-// and the greedy sweep; plus the generic elementwise focal BCE.
+// class max + score threshold + candidate compaction (on the flat [B,N,C] tensor or on
+// the heads' per-level [B, A*C, H, W] outputs), per-image sort, bitmask NMS and the
+// greedy sweep.
 //
 // Reference behaviour restated here: models/retinanet/utils.py:96-120 (decode),
 // :133-142 (clip), models/retinanet/model.py:320-340 (post-processing) and the
 // contract of torchvision.ops.nms called at model.py:336 (greedy; a box is dropped
 // when its IoU with a kept, higher-scoring box is > threshold; ties in score keep
-// the lower index first); models/focal_loss.py:14-25 (generic focal BCE).
+// the lower index first).
 //
 // Compiled with -ffp-contract=off: box coordinates and IoU values decide integer
 // keep lists that must match a float32 CPU evaluation bit for bit.

@@ -1,5 +1,6 @@
 // Training half of the dense-head path on gfx950: GT compaction, anchor x GT IoU
-// assignment, and the fused focal + smooth-L1 forward/backward stream.
+// assignment, and the fused focal + smooth-L1 forward/backward stream (on the flat
+// [B,N,C] / [B,N,4] tensors or on the heads' per-level [B, A*C, H, W] outputs).
 //
 // Reference behaviour restated here: models/retinanet/losses.py:6-23 (IoU),
 // :48-49 (GT filter), :57 (clamp), :59-61 (max/argmax), :67-94 (targets, focal
@@ -12,7 +13,7 @@
 
 namespace rh {
 
-// One valid ground-truth box, as staged by gt_prepare_kernel (32 bytes).
+// One valid ground-truth box, as compacted by assign_kernel (32 bytes).
 struct __attribute__((aligned(16))) GtRec {
   float x1, y1, x2, y2;
   float area;
