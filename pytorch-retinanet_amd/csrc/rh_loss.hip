@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const int split = (j0 + 1) * N - row0;            // first tile-local row of image j0+1
     const bool two = split < rows;
     // the tile's codes and the positive counts go out together: one memory latency, not two
-    const int my_code_raw = code[min(row0 + tid, total_rows - 1)];
+    const int my_code_raw = code[min(row0 + min(tid, kTileRows - 1), total_rows - 1)];
     // positives of the tile's image(s): sum of the assignment kernel's per-block counts
     int v0 = 0, v1 = 0;
     for (int i = tid; i < nblk; i += kThreads) {
