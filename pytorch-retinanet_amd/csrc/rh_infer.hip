@@ -1587,6 +1587,9 @@ int rh_postprocess_levels(const float* const* cls_levels, const float* const* re
   RH_REQUIRE((stages & ~RH_POST_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
   for (int l = 0; l < num_levels; ++l) {
     RH_REQUIRE(cls_levels[l] && reg_levels[l], RH_EINVAL, "null pointer for level %d", l);
+    // offsets inside one image's [A*C, H*W] block are 32-bit in the kernel
+    RH_REQUIRE((long long)anchors_per_cell * num_classes * g.hw[l] < (1ll << 31), RH_ESHAPE,
+               "level %d: A*C*H*W does not fit 31 bits", l);
     g.cls[l] = cls_levels[l];
     g.reg[l] = reg_levels[l];
     g.vec4[l] = g.hw[l] % 4 == 0 && aligned16(cls_levels[l]);

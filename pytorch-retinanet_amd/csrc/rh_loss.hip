@@ -1263,6 +1263,9 @@ int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* co
   LevelTable lt{};
   lt.num_levels = num_levels;
   for (int l = 0; l < num_levels; ++l) {
+    // offsets inside one image's [A*C, H*W] block are 32-bit in the kernel
+    RH_REQUIRE((long long)anchors_per_cell * num_classes * lp.hw[l] < (1ll << 31), RH_ESHAPE,
+               "level %d: A*C*H*W does not fit 31 bits", l);
     RH_REQUIRE(cls_levels[l] && reg_levels[l] && d_cls_levels[l] && d_reg_levels[l], RH_EINVAL,
                "null pointer for level %d", l);
     lt.cls[l] = cls_levels[l];
