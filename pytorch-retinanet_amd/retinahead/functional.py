@@ -195,7 +195,8 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
                        neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
                        batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False):
     """Runs the fused loss kernels.  Returns a dict of device tensors:
-    losses [2], per_image [2,B], num_pos [B], status [B], d_classifications, d_regressions.
+    losses [2], total [1] (their sum; adjacent in memory), per_image [2,B], num_pos [B], status [B],
+    d_classifications, d_regressions.
     ``out`` may carry buffers from an earlier call (used when stages are run one at a time).
     """
     dev = _dev_check(classifications, regressions, anchors_t, annotations)
@@ -212,12 +213,13 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     lib = _lib.load()
     if out is None:
         # one small allocation for all scalar-ish outputs: [losses 2 | per_image 2B | num_pos B | status B]
-        small = torch.empty((2 + 4 * bsz,), dtype=torch.float32, device=dev)
+        small = torch.empty((3 + 4 * bsz,), dtype=torch.float32, device=dev)
         out = dict(
             losses=small[0:2],
-            per_image=small[2:2 + 2 * bsz].view(2, bsz),
-            num_pos=small[2 + 2 * bsz:2 + 3 * bsz].view(torch.int32),
-            status=small[2 + 3 * bsz:].view(torch.int32),
+            total=small[2:3],
+            per_image=small[3:3 + 2 * bsz].view(2, bsz),
+            num_pos=small[3 + 2 * bsz:3 + 3 * bsz].view(torch.int32),
+            status=small[3 + 3 * bsz:].view(torch.int32),
             d_classifications=torch.empty_like(cls),
             d_regressions=torch.empty_like(reg),
         )
@@ -274,7 +276,7 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
     nl = len(cls)
     lib = _lib.load()
     if out is None:
-        small = torch.empty((2 + 4 * bsz,), dtype=torch.float32, device=dev)
+        small = torch.empty((3 + 4 * bsz,), dtype=torch.float32, device=dev)
         d_cls_all = torch.empty((sum(t.numel() for t in cls),), dtype=torch.float32, device=dev)
         d_reg_all = torch.empty((sum(t.numel() for t in reg),), dtype=torch.float32, device=dev)
 
@@ -286,9 +288,10 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
             return res
         out = dict(
             losses=small[0:2],
-            per_image=small[2:2 + 2 * bsz].view(2, bsz),
-            num_pos=small[2 + 2 * bsz:2 + 3 * bsz].view(torch.int32),
-            status=small[2 + 3 * bsz:].view(torch.int32),
+            total=small[2:3],
+            per_image=small[3:3 + 2 * bsz].view(2, bsz),
+            num_pos=small[3 + 2 * bsz:3 + 3 * bsz].view(torch.int32),
+            status=small[3 + 3 * bsz:].view(torch.int32),
             d_cls_all=d_cls_all, d_reg_all=d_reg_all,
             d_cls_levels=views(d_cls_all, cls), d_reg_levels=views(d_reg_all, reg),
         )

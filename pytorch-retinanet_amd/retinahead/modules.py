@@ -20,6 +20,61 @@ def calc_iou(a, b):
     return F.calc_iou(a, b)
 
 
+class _LossPair:
+    """The two losses of one forward call and their sum as the kernel already formed it."""
+    __slots__ = ("cls", "reg", "total")
+
+
+class _LossTensor(torch.Tensor):
+    """A [1] loss tensor that knows its partner.  ``train.py:185`` adds the two losses
+    (``sum(loss_dict.values())``: ``0 + classification_loss + regression_loss``); the finalize
+    kernel has formed that float32 sum already, so ``0 + loss`` returns the loss itself and
+    ``classification_loss + regression_loss`` returns the stored total, a third output of the
+    same autograd node: two one-element launches less per step, same values, same gradients.
+    Every other operation behaves as on a plain tensor and returns plain tensors."""
+
+    _pair = None
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if not kwargs and len(args) == 2 and func in _ADD_FUNCS:
+            a, b = args
+            if isinstance(a, _LossTensor) and _is_zero(b):
+                return a
+            if isinstance(b, _LossTensor) and _is_zero(a):
+                return b
+            if isinstance(a, _LossTensor) and isinstance(b, _LossTensor) and a is not b \
+                    and a._pair is not None and a._pair is b._pair:
+                return a._pair.total
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return out.as_subclass(torch.Tensor) if isinstance(out, _LossTensor) else out
+
+
+_ADD_FUNCS = (torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.add)
+
+
+def _is_zero(x):
+    return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 0
+
+
+def _as_loss_dict(cls_loss, reg_loss, total):
+    pair = _LossPair()
+    pair.cls = cls_loss.as_subclass(_LossTensor)
+    pair.reg = reg_loss.as_subclass(_LossTensor)
+    pair.total = total
+    pair.cls._pair = pair.reg._pair = pair
+    return {"classification_loss": pair.cls, "regression_loss": pair.reg}
+
+
+def _upstream(g_part, g_total):
+    """Gradient reaching one loss: directly, through the stored total, or both."""
+    if g_part is None:
+        return g_total
+    return g_part if g_total is None else g_part + g_total
+
+
 class _DenseHeadLossFn(torch.autograd.Function):
     """Forward launches the fused forward+backward kernels and keeps the gradients;
     backward applies the upstream gradients to them in place (one launch, no host read)."""
@@ -38,11 +93,13 @@ class _DenseHeadLossFn(torch.autograd.Function):
         # keep only the small outputs: a second reference to the gradient buffers would make
         # autograd's AccumulateGrad copy them (hundreds of MB) instead of adopting them
         cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
+        ctx.set_materialize_grads(False)
         losses = out["losses"]          # fresh storage every call: views need no copy
-        return losses[0:1], losses[1:2]
+        return losses[0:1], losses[1:2], out["total"]
 
     @staticmethod
-    def backward(ctx, g_cls, g_reg):
+    def backward(ctx, g_cls, g_reg, g_total):
+        g_cls, g_reg = _upstream(g_cls, g_total), _upstream(g_reg, g_total)
         if ctx.d_cls is None:
             raise RetinaHeadError("the fused loss keeps one set of gradients: backward() can run "
                                   "once per forward()")
@@ -72,11 +129,13 @@ class _DenseHeadLevelsLossFn(torch.autograd.Function):
         ctx.expected = cfg["expected_grad"]
         ctx.in_dtypes = [t.dtype for t in levels]
         cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
+        ctx.set_materialize_grads(False)
         losses = out["losses"]
-        return losses[0:1], losses[1:2]
+        return losses[0:1], losses[1:2], out["total"]
 
     @staticmethod
-    def backward(ctx, g_cls, g_reg):
+    def backward(ctx, g_cls, g_reg, g_total):
+        g_cls, g_reg = _upstream(g_cls, g_total), _upstream(g_reg, g_total)
         if ctx.flat is None:
             raise RetinaHeadError("the fused loss keeps one set of gradients: backward() can run "
                                   "once per forward()")
@@ -128,12 +187,12 @@ class FocalLoss(nn.Module):
         return self.cfg["last"]
 
     def forward(self, classifications, regressions, anchors, annotations):
-        cls_loss, reg_loss = _DenseHeadLossFn.apply(classifications, regressions, anchors,
-                                                    annotations, self.cfg)
+        cls_loss, reg_loss, total = _DenseHeadLossFn.apply(classifications, regressions, anchors,
+                                                           annotations, self.cfg)
         if self.check_labels:
             if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
                 raise IndexError("annotation label outside [0, num_classes)")
-        return {"classification_loss": cls_loss, "regression_loss": reg_loss}
+        return _as_loss_dict(cls_loss, reg_loss, total)
 
     def forward_levels(self, cls_levels, reg_levels, anchors, annotations):
         """The same loss on the heads' per-level outputs, without the permute / view / cat of
@@ -141,12 +200,12 @@ class FocalLoss(nn.Module):
         convolution's output [B, A*C, H_l, W_l] (probabilities, or logits with ``from_logits``),
         ``reg_levels[l]`` the regression convolution's [B, A*4, H_l, W_l], levels in the order of
         the anchors.  Gradients arrive in the same layouts."""
-        cls_loss, reg_loss = _DenseHeadLevelsLossFn.apply(self.cfg, anchors, annotations,
-                                                          len(cls_levels), *cls_levels, *reg_levels)
+        cls_loss, reg_loss, total = _DenseHeadLevelsLossFn.apply(
+            self.cfg, anchors, annotations, len(cls_levels), *cls_levels, *reg_levels)
         if self.check_labels:
             if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
                 raise IndexError("annotation label outside [0, num_classes)")
-        return {"classification_loss": cls_loss, "regression_loss": reg_loss}
+        return _as_loss_dict(cls_loss, reg_loss, total)
 
 
 class _GenericFocalFn(torch.autograd.Function):

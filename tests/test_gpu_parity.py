@@ -242,6 +242,52 @@ def test_loss_on_head_layout(rh, size, c, from_logits):
     assert np.allclose(out["regression_loss"].item(), ref["regression_loss"][0], rtol=RTOL)
 
 
+def test_loss_sum_uses_the_stored_total(rh, focal_golden):
+    """train.py:185-190: sum(loss_dict.values()).backward().  The sum is the total the finalize
+    kernel stored (no add launches), bit-equal to cls + reg, and back-propagates like it."""
+    d = focal_golden["normal"]
+    args = (dev(d["anchors"]), dev(d["ann"]))
+    grads = []
+    for how in ("sum", "plain_add", "scaled", "separate"):
+        cls = dev(d["cls"]).requires_grad_(True)
+        reg = dev(d["reg"]).requires_grad_(True)
+        out = rh.FocalLoss()(cls, reg, *args)
+        c, r = out["classification_loss"], out["regression_loss"]
+        assert c.shape == (1,) and r.shape == (1,) and c.grad_fn is not None
+        if how == "sum":
+            loss = sum(l for l in out.values())
+            assert type(loss) is torch.Tensor and loss.shape == (1,)
+            assert loss.item() == (c.detach().clone() + r.detach().clone()).item()
+            assert sum(out.values()).data_ptr() == loss.data_ptr()       # the stored total, no new tensor
+        elif how == "plain_add":
+            loss = c + r
+        elif how == "scaled":
+            loss = (c * 1.0 + r).mean()                                  # ordinary autograd path
+        else:
+            loss = None
+            torch.autograd.backward([c, r], [torch.ones_like(c), torch.ones_like(r)])
+        if loss is not None:
+            loss.backward()
+        grads.append((cls.grad.clone(), reg.grad.clone()))
+        assert isinstance(float(c), float) and isinstance(c.item(), float)
+    for gc, gr in grads[1:]:
+        assert torch.equal(gc, grads[0][0]) and torch.equal(gr, grads[0][1])
+    grad_close(grads[0][0].cpu().numpy(), d["d_cls"] / d["g"][0])
+    # using the total AND one part: the part's gradient counts twice
+    cls = dev(d["cls"]).requires_grad_(True)
+    reg = dev(d["reg"]).requires_grad_(True)
+    out = rh.FocalLoss()(cls, reg, *args)
+    (sum(out.values()) + out["classification_loss"]).sum().backward()
+    assert torch.allclose(cls.grad, 2 * grads[0][0], rtol=1e-6, atol=0)
+    assert torch.equal(reg.grad, grads[0][1])
+    # gradient accumulation, train.py:187-190
+    cls = dev(d["cls"]).requires_grad_(True)
+    reg = dev(d["reg"]).requires_grad_(True)
+    out = rh.FocalLoss(expected_grad=0.25)(cls, reg, *args)
+    (sum(out.values()) / 4).backward()
+    assert torch.allclose(cls.grad, grads[0][0] / 4, rtol=1e-6, atol=0)
+
+
 def test_loss_deterministic_and_unaligned(rh):
     cls, reg, anc, ann = make_batch(3, 2, 128, 80, 5, [5, 2])
     a = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
