@@ -20,11 +20,6 @@ def calc_iou(a, b):
     return F.calc_iou(a, b)
 
 
-class _LossPair:
-    """The two losses of one forward call and their sum as the kernel already formed it."""
-    __slots__ = ("cls", "reg", "total")
-
-
 class _LossTensor(torch.Tensor):
     """A [1] loss tensor that knows its partner.  ``train.py:185`` adds the two losses
     (``sum(loss_dict.values())``: ``0 + classification_loss + regression_loss``); the finalize
@@ -33,7 +28,8 @@ class _LossTensor(torch.Tensor):
     same autograd node: two one-element launches less per step, same values, same gradients.
     Every other operation behaves as on a plain tensor and returns plain tensors."""
 
-    _pair = None
+    _token = None      # shared by the two losses of one forward call (and by nothing else)
+    _total = None      # their sum as the finalize kernel stored it
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -45,8 +41,8 @@ class _LossTensor(torch.Tensor):
             if isinstance(b, _LossTensor) and _is_zero(a):
                 return b
             if isinstance(a, _LossTensor) and isinstance(b, _LossTensor) and a is not b \
-                    and a._pair is not None and a._pair is b._pair:
-                return a._pair.total
+                    and a._token is not None and a._token is b._token:
+                return a._total
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         return out.as_subclass(torch.Tensor) if isinstance(out, _LossTensor) else out
@@ -60,12 +56,12 @@ def _is_zero(x):
 
 
 def _as_loss_dict(cls_loss, reg_loss, total):
-    pair = _LossPair()
-    pair.cls = cls_loss.as_subclass(_LossTensor)
-    pair.reg = reg_loss.as_subclass(_LossTensor)
-    pair.total = total
-    pair.cls._pair = pair.reg._pair = pair
-    return {"classification_loss": pair.cls, "regression_loss": pair.reg}
+    # no reference from one loss to the other (that would be a cycle through the autograd node,
+    # which owns the gradient buffers, and only the cyclic collector would ever free them)
+    c, r = cls_loss.as_subclass(_LossTensor), reg_loss.as_subclass(_LossTensor)
+    c._token = r._token = object()
+    c._total = r._total = total
+    return {"classification_loss": c, "regression_loss": r}
 
 
 def _upstream(g_part, g_total):

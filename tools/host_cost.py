@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Host time (enqueue only) of the pieces of an eager FocalLoss step, at a tiny size so that
+the GPU never is the bottleneck."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pytorch-retinanet_amd")):
+    sys.path.insert(0, p)
+import bench  # noqa: E402
+import retinahead as rh  # noqa: E402
+from retinahead import _lib, functional as F  # noqa: E402
+
+dev = torch.device("cuda:0")
+anchors = rh.Anchors()(torch.zeros(1, 3, 64, 64, device=dev))
+n = anchors.shape[1]
+cls_np, reg_np, ann_np = bench.synth_train(np.random.default_rng(0), 16, n, 80, 64, 20)
+cls = torch.from_numpy(cls_np).to(dev).requires_grad_(True)
+reg = torch.from_numpy(reg_np).to(dev).requires_grad_(True)
+ann = torch.from_numpy(ann_np).to(dev)
+mod = rh.FocalLoss()
+
+
+def timeit(name, fn, n=300):
+    import gc
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    gc.collect()
+    before = sum(s["collections"] for s in gc.get_stats())
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    runs = sum(s["collections"] for s in gc.get_stats()) - before
+    print(f"{name:48s} {1e6 * (t1 - t0) / n:7.1f} us   (cyclic GC ran {runs}x)")
+
+
+bufs = F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann)
+timeit("functional fwd_bwd, buffers reused", lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann, out=bufs))
+timeit("functional fwd_bwd, fresh buffers", lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann))
+for st, nm in ((_lib.STAGE_ASSIGN, "assign"), (_lib.STAGE_STREAM, "stream"), (_lib.STAGE_FINALIZE, "finalize")):
+    timeit(f"  stage {nm} only", lambda st=st: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann, out=bufs, stages=st))
+timeit("module forward (autograd node)", lambda: mod(cls, reg, anchors, ann))
+
+
+def step():
+    cls.grad = None
+    reg.grad = None
+    out = mod(cls, reg, anchors, ann)
+    sum(out.values()).backward()
+
+
+timeit("module forward + sum + backward", step)
+one = torch.ones(1, device=dev)
+timeit("apply_upstream", lambda: F.apply_upstream(bufs["d_classifications"], one, bufs["d_regressions"], one))
+timeit("torch.empty_like(cls)", lambda: torch.empty_like(cls))
+x = torch.zeros(8, device=dev)
+timeit("a tiny torch kernel (x.add_(1))", lambda: x.add_(1))
+
+import cProfile, pstats
+with torch.no_grad():
+    timeit("module forward under no_grad", lambda: mod(cls, reg, anchors, ann))
+cd, rd = cls.detach(), reg.detach()
+timeit("module forward, inputs without grad", lambda: mod(cd, rd, anchors, ann))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(200):
+    mod(cls, reg, anchors, ann)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
