@@ -126,7 +126,20 @@ int rh_assign(const float* anchors, const float* annotations, int32_t batch, int
  *   status          device i32 [B] or NULL  (rh_status_bits per image, written by every call)
  * batch_divisor: number of images the batch mean runs over; 0 means B.  A
  * data-parallel shard passes the global batch size.
+ *
+ * normalizer = RH_NORM_GLOBAL replaces the reference's per-image normalisers (losses.py:94,
+ * :134) and batch mean (:139-141) by one positive count P for the whole batch:
+ *   classification_loss = sum over images of the focal sums / max(P, 1),
+ *   regression_loss     = sum over images of the smooth-L1 sums / (4 P)   (0 when P == 0),
+ * per_image[.., j] is image j's share of those sums, batch_divisor is not used.  The reference
+ * has no such mode; with equal positive counts in every image both modes agree.  P is
+ * *num_pos_total when that pointer is given, else the positives of this call's images, counted
+ * on the device in the RH_STAGE_ASSIGN stage (which then also writes num_pos).  A data-parallel
+ * shard runs RH_STAGE_ASSIGN, sums num_pos over all ranks, and passes the result as
+ * num_pos_total to the remaining stages; its losses are then its share of the global ones.
  * ------------------------------------------------------------------------- */
+enum rh_normalizer { RH_NORM_PER_IMAGE = 0, RH_NORM_GLOBAL = 1 };
+
 typedef struct rh_focal_params {
   float alpha;          /* 0.25  losses.py:30 (gamma is fixed at 2, :31) */
   float neg_thresh;     /* 0.4   losses.py:70 */
@@ -138,6 +151,8 @@ typedef struct rh_focal_params {
                            1: they are logits; the head's nn.Sigmoid (model.py:177, 193) is folded
                            into the stream, d_classifications is the gradient with respect to the
                            logits (dL/dp * p * (1 - p), as autograd through torch.sigmoid). */
+  int32_t normalizer;   /* rh_normalizer; RH_NORM_PER_IMAGE is the reference */
+  const float* num_pos_total; /* device f32 [1] or NULL; RH_NORM_GLOBAL only */
 } rh_focal_params;
 
 void rh_focal_params_default(rh_focal_params* p);

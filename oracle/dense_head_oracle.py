@@ -210,7 +210,7 @@ def sigmoid_f32(x):
 
 def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
                        alpha=0.25, grad_cls=1.0, grad_reg=1.0, batch_divisor=None,
-                       from_logits=False):
+                       from_logits=False, normalizer="per_image", num_pos_total=None):
     """Losses and gradients for a batch (gamma is 2 as in losses.py:31).
 
     Returns dict with
@@ -224,7 +224,16 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
     ``from_logits``: classifications are the head's logits; the sigmoid of model.py:177,193
     is applied first and d_classifications is the gradient with respect to the logits
     (chain rule through the sigmoid, dp/dx = p (1 - p), as autograd applies it).
+    ``normalizer='global'`` (no counterpart in the reference, whose normalisers are per image,
+    losses.py:94, :134): one positive count P for the whole batch -- ``num_pos_total`` if given
+    (a data-parallel shard passes the count over all ranks), else this batch's positives --
+    replaces the per-image counts and the batch mean: classification_loss = sum of the images'
+    focal sums / max(P, 1), regression_loss = sum of their smooth-L1 sums / (4 P); the
+    per-image outputs are the images' shares; ``batch_divisor`` is not used.
     """
+    if normalizer not in ("per_image", "global"):
+        raise ValueError("normalizer must be 'per_image' or 'global'")
+    batch_wide = normalizer == "global"
     logits_in = bool(from_logits)
     if logits_in:
         classifications = sigmoid_f32(classifications)
@@ -233,19 +242,23 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
     anc = np.asarray(anchors, dtype=F32).reshape(-1, 4)
     ann = np.asarray(annotations, dtype=F32)
     bsz, n, c = cls.shape
-    div = float(bsz if batch_divisor is None else batch_divisor)
+    div = 1.0 if batch_wide else float(bsz if batch_divisor is None else batch_divisor)
+    assigned = [assign(anc, ann[j]) for j in range(bsz)]
+    if batch_wide:
+        total = (sum(int(a["num_pos"]) for a in assigned) if num_pos_total is None
+                 else int(num_pos_total))
     d_cls = np.zeros_like(cls)
     d_reg = np.zeros_like(reg)
     cls_img = np.zeros(bsz, F32)
     reg_img = np.zeros(bsz, F32)
     npos = np.zeros(bsz, np.int32)
     for j in range(bsz):
-        asg = assign(anc, ann[j])
+        asg = assigned[j]
         npos[j] = asg["num_pos"]
         if asg["num_gt"] == 0:
             continue                                            # losses.py:51-55
         loss, grad = _focal_image(cls[j], asg["state"], asg["label"], alpha)
-        norm = F32(max(asg["num_pos"], 1))
+        norm = F32(max(total if batch_wide else asg["num_pos"], 1))
         cls_img[j] = F32(loss.sum(dtype=np.float64)) / norm     # losses.py:94
         d_cls[j] = grad * (F32(grad_cls) / (norm * F32(div)))
         if logits_in:
@@ -258,7 +271,7 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors, annotations,
             d = np.abs(delta).astype(F32)
             small = d <= F32(1.0 / 9.0)
             elem = np.where(small, F32(0.5 * 9.0) * (d * d), d - F32(0.5 / 9.0)).astype(F32)
-            count = F32(4 * asg["num_pos"])
+            count = F32(4 * (total if batch_wide else asg["num_pos"]))
             reg_img[j] = F32(elem.sum(dtype=np.float64)) / count
             g = np.where(small, F32(9.0) * d, F32(1)) * np.sign(delta)
             d_reg[j][pos] = (g * (F32(grad_reg) / (count * F32(div)))).astype(F32)

@@ -36,6 +36,8 @@ void rh_focal_params_default(rh_focal_params* p) {
   p->grad_reg = 1.0f;
   p->batch_divisor = 0;
   p->from_logits = 0;
+  p->normalizer = RH_NORM_PER_IMAGE;
+  p->num_pos_total = NULL;
 }
 
 void rh_anchor_cfg_default(rh_anchor_cfg* cfg) {

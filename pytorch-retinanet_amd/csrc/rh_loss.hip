@@ -280,6 +280,32 @@ __global__ __launch_bounds__(kThreads) void sum_blk_pos_kernel(const int* __rest
   if (threadIdx.x == 0) num_pos[blockIdx.x] = t;
 }
 
+// Batch-wide normaliser: per-image positive counts and their total as a float (exact below
+// 2^24 positives).  One workgroup; image j is summed by wave j % 4, lane-strided, so the result
+// does not depend on timing.
+__global__ __launch_bounds__(kThreads) void count_positives_kernel(const int* __restrict__ blk_pos,
+                                                                   int nblk, int B,
+                                                                   int* __restrict__ num_pos,
+                                                                   float* __restrict__ total) {
+  __shared__ int s_tot[kThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int acc = 0;
+  for (int j = wave; j < B; j += kThreads / 64) {
+    int v = 0;
+    for (int i = lane; i < nblk; i += 64) v += blk_pos[(size_t)j * nblk + i];
+    v = wave_sum(v);
+    if (lane == 0 && num_pos) num_pos[j] = v;
+    acc += v;
+  }
+  if (lane == 0) s_tot[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < kThreads / 64; ++w) t += s_tot[w];
+    *total = (float)t;
+  }
+}
+
 // Full IoU matrix (losses.py:6-23), one thread per output element.
 __global__ __launch_bounds__(kThreads) void calc_iou_kernel(const float4* __restrict__ a,
                                                             const float4* __restrict__ b,
@@ -422,7 +448,8 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
     float* __restrict__ partials, int N, int C, int M, int total_rows, int num_tiles,
-    unsigned magic_c, FocalConst fc, float gcls, float greg, float divisor) {
+    unsigned magic_c, FocalConst fc, float gcls, float greg, float divisor,
+    const float* __restrict__ pos_total) {
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
   __shared__ int s_np[kThreads / 64][2];
@@ -439,11 +466,14 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     // the tile's codes and the positive counts go out together: one memory latency, not two
     const int my_code_raw = code[min(row0 + min(tid, kTileRows - 1), total_rows - 1)];
     // positives of the tile's image(s): sum of the assignment kernel's per-block counts
+    // (with a batch-wide normaliser every image uses the one total instead)
+    const float total = pos_total ? *pos_total : 0.f;
     int v0 = 0, v1 = 0;
-    for (int i = tid; i < nblk; i += kThreads) {
-      v0 += blk_pos[(size_t)j0 * nblk + i];
-      if (two) v1 += blk_pos[(size_t)(j0 + 1) * nblk + i];
-    }
+    if (!pos_total)
+      for (int i = tid; i < nblk; i += kThreads) {
+        v0 += blk_pos[(size_t)j0 * nblk + i];
+        if (two) v1 += blk_pos[(size_t)(j0 + 1) * nblk + i];
+      }
     v0 = wave_sum(v0);
     v1 = wave_sum(v1);
 
@@ -456,9 +486,9 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     if (tid < kTileRows) s_code[tid] = tid < rows ? my_code : kCodeIgn;
     // any positive or ignored row in this tile?  (also the barrier that publishes s_code, s_np)
     const int special = __syncthreads_or(my_code != kCodeNeg);
-    const int np0 = (s_np[0][0] + s_np[1][0]) + (s_np[2][0] + s_np[3][0]);
-    const int np1 = (s_np[0][1] + s_np[1][1]) + (s_np[2][1] + s_np[3][1]);
-    const float norm0 = (float)max(np0, 1), norm1 = (float)max(np1, 1);
+    const float np0 = pos_total ? total : (float)((s_np[0][0] + s_np[1][0]) + (s_np[2][0] + s_np[3][0]));
+    const float np1 = pos_total ? total : (float)((s_np[0][1] + s_np[1][1]) + (s_np[2][1] + s_np[3][1]));
+    const float norm0 = fmaxf(np0, 1.f), norm1 = fmaxf(np1, 1.f);
     const float sc0 = gcls / (norm0 * divisor), sc1 = gcls / (norm1 * divisor);
 
     float cl0 = 0.f, cl1 = 0.f, rl0 = 0.f, rl1 = 0.f;
@@ -474,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
           if (cd >= 0) {
             const bool second = r >= split;
             const int j = second ? j0 + 1 : j0;
-            const float cnt4 = 4.0f * (float)(second ? np1 : np0);
+            const float cnt4 = 4.0f * (second ? np1 : np0);
             const float rv = reg[(size_t)grow * 4 + k];
             float gr;
             const float l = smooth_l1_coord(k, anchors[grow - j * N],
@@ -621,15 +651,15 @@ __global__ __launch_bounds__(kThreads) void focal_rows_kernel(
     float* __restrict__ dreg, const float* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
     float* __restrict__ partials, int N, int C, int M, FocalConst fc, float gcls, float greg,
-    float divisor) {
+    float divisor, const float* __restrict__ pos_total) {
   __shared__ float s_red[4];
   __shared__ int s_tmp[kThreads / 64];
   const int j = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int np = sum_blk_pos(blk_pos, nblk, j, s_tmp);
-  const float sc = gcls / ((float)max(np, 1) * divisor);
-  const float rsc = greg / ((4.0f * (float)np) * divisor);
+  const float np = pos_total ? *pos_total : (float)sum_blk_pos(blk_pos, nblk, j, s_tmp);
+  const float sc = gcls / (fmaxf(np, 1.f) * divisor);
+  const float rsc = greg / ((4.0f * np) * divisor);
   float cl = 0.f, rl = 0.f;
   for (int n = blockIdx.x * (kThreads / 64) + wave; n < N; n += gridDim.x * (kThreads / 64)) {
     const size_t row = (size_t)j * N + n;
@@ -715,7 +745,7 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
     LevelTable lt, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
     float* __restrict__ partials, int N, int A, int C, int M, FocalConst fc, float gcls, float greg,
-    float divisor) {
+    float divisor, const float* __restrict__ pos_total) {
   __shared__ float s_red[kLvlThreads / 64];
   __shared__ int s_tmp[kLvlThreads / 64];
   const int tid = threadIdx.x;
@@ -779,9 +809,9 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
     if (!ok[k]) cd[k] = kCodeNeg;
     special |= cd[k] != kCodeNeg;
   }
-  const int np = sum_blk_pos(blk_pos, nblk, j, s_tmp);
-  const float sc = gcls / ((float)max(np, 1) * divisor);
-  const float rsc = greg / ((4.0f * (float)np) * divisor);
+  const float np = pos_total ? *pos_total : (float)sum_blk_pos(blk_pos, nblk, j, s_tmp);
+  const float sc = gcls / (fmaxf(np, 1.f) * divisor);
+  const float rsc = greg / ((4.0f * np) * divisor);
   // decide per wave, not per lane: a wave with a single positive or ignored unit would
   // otherwise run both element paths one after the other
   special = __ballot(special) != 0ull;
@@ -892,7 +922,8 @@ constexpr int kFinalThreads = 1024;
 __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     const float* __restrict__ partials, const int* __restrict__ blk_pos, int nblk,
     const int* __restrict__ gt_count, float* __restrict__ per_image, int* __restrict__ num_pos_out,
-    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor) {
+    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor,
+    const float* __restrict__ pos_total) {
   __shared__ float s_img[2][kFinalThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double bc = 0.0, br = 0.0;     // wave 0 only: batch sums, images visited in ascending order
@@ -926,8 +957,11 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
       r = wave_sum(r);
       np = wave_sum(np);
       const bool empty = gt_count[j] == 0;
-      cl = empty ? 0.f : (float)c / (float)max(np, 1);
-      rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * (float)np);
+      // batch-wide normaliser: every image is divided by the one total (an image's share of
+      // the batch loss); otherwise by its own count, losses.py:94 and :134
+      const float npf = pos_total ? *pos_total : (float)np;
+      cl = empty ? 0.f : (float)c / fmaxf(npf, 1.f);
+      rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * npf);
       if (lane == 0) {
         if (per_image) {
           per_image[j] = cl;
@@ -991,6 +1025,7 @@ struct LossWorkspace {
   int nblk;
   int* code;
   float* partials;
+  float* pos_total;  // [1] positives of the whole call (batch-wide normaliser only)
   size_t bytes;
 };
 
@@ -1011,6 +1046,7 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
+  w.pos_total = cv.take<float>(1);
   w.bytes = cv.off;
   return w;
 }
@@ -1089,8 +1125,38 @@ static LossWorkspace carve_levels(void* ws, int batch, long long n, int m, long 
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)batch * blocks * 2);
+  w.pos_total = cv.take<float>(1);
   w.bytes = cv.off;
   return w;
+}
+
+// How the call normalises: per image (the reference) or by one batch-wide positive count.
+struct Normaliser {
+  const float* total;   // device f32 [1]; null = per image
+  float divisor;        // images the batch mean runs over (1 with a batch-wide count)
+};
+
+static int resolve_normaliser(const rh_focal_params* p, int batch, const LossWorkspace& w,
+                              Normaliser* out) {
+  RH_REQUIRE(p->batch_divisor >= 0, RH_EINVAL, "batch_divisor < 0");
+  RH_REQUIRE(p->normalizer == RH_NORM_PER_IMAGE || p->normalizer == RH_NORM_GLOBAL, RH_EINVAL,
+             "normalizer=%d is neither RH_NORM_PER_IMAGE nor RH_NORM_GLOBAL", p->normalizer);
+  if (p->normalizer == RH_NORM_GLOBAL) {
+    out->total = p->num_pos_total ? p->num_pos_total : w.pos_total;
+    out->divisor = 1.0f;
+  } else {
+    RH_REQUIRE(!p->num_pos_total, RH_EINVAL, "num_pos_total given without RH_NORM_GLOBAL");
+    out->total = nullptr;
+    out->divisor = (float)(p->batch_divisor > 0 ? p->batch_divisor : batch);
+  }
+  return RH_OK;
+}
+
+static int launch_count(const LossWorkspace& w, int batch, int* num_pos, hipStream_t s) {
+  hipLaunchKernelGGL(count_positives_kernel, dim3(1), dim3(kThreads), 0, s, w.blk_pos, w.nblk, batch,
+                     num_pos, w.pos_total);
+  RH_CHECK_LAUNCH("count_positives_kernel");
+  return RH_OK;
 }
 
 }  // namespace rh
@@ -1172,12 +1238,13 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
-  RH_REQUIRE(params->batch_divisor >= 0, RH_EINVAL, "batch_divisor < 0");
   RH_REQUIRE((stages & ~RH_STAGE_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
 
   hipStream_t s = (hipStream_t)stream;
   const LossWorkspace w = carve_loss(workspace, batch, n, num_classes, m);
-  const float divisor = (float)(params->batch_divisor > 0 ? params->batch_divisor : batch);
+  Normaliser nrm;
+  if (int e = resolve_normaliser(params, batch, w, &nrm)) return e;
+  const float divisor = nrm.divisor;
   const FocalConst fc{params->alpha, 1e-4f, (float)(1.0 - 1e-4)};
   const bool tile = tile_path_ok(n, num_classes) && aligned16(classifications) &&
                     aligned16(d_classifications);
@@ -1189,6 +1256,8 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                               params->pos_thresh, w, w.code, nullptr, nullptr, nullptr, nullptr,
                               status, s))
       return e;
+    if (params->normalizer == RH_NORM_GLOBAL)
+      if (int e = launch_count(w, batch, num_pos, s)) return e;
   }
   if (stages & RH_STAGE_STREAM) {
     if (tile) {
@@ -1206,21 +1275,21 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
                          div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
-                         divisor);
+                         divisor, nrm.total);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
       auto kern = params->from_logits ? focal_rows_kernel<true> : focal_rows_kernel<false>;
       hipLaunchKernelGGL(kern, dim3(kGenericBlocks, batch), dim3(kThreads), 0, s,
                          classifications, d_classifications, regressions, d_regressions, anchors,
                          w.gt, w.code, w.blk_pos, w.nblk, w.partials, (int)n, num_classes, m, fc,
-                         params->grad_cls, params->grad_reg, divisor);
+                         params->grad_cls, params->grad_reg, divisor, nrm.total);
       RH_CHECK_LAUNCH("focal_rows_kernel");
     }
   }
   if (stages & RH_STAGE_FINALIZE) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
                        w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n, tile ? 1 : 0,
-                       kGenericBlocks, divisor);
+                       kGenericBlocks, divisor, nrm.total);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;
@@ -1258,7 +1327,6 @@ int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* co
   RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
-  RH_REQUIRE(params->batch_divisor >= 0, RH_EINVAL, "batch_divisor < 0");
   RH_REQUIRE((stages & ~RH_STAGE_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
   RH_REQUIRE(blocks < (1ll << 24), RH_ESHAPE, "too many workgroups per image");
 
@@ -1285,7 +1353,9 @@ int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* co
   hipStream_t s = (hipStream_t)stream;
   const LossWorkspace w = carve_levels(workspace, batch, lp.n, m,
                                        (long long)lp.chunks * 16);
-  const float divisor = (float)(params->batch_divisor > 0 ? params->batch_divisor : batch);
+  Normaliser nrm;
+  if (int e = resolve_normaliser(params, batch, w, &nrm)) return e;
+  const float divisor = nrm.divisor;
   const FocalConst fc{params->alpha, 1e-4f, (float)(1.0 - 1e-4)};
   if (stages & RH_STAGE_ASSIGN) {
     CodeLayout lay{};
@@ -1300,19 +1370,21 @@ int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* co
                               params->pos_thresh, w, w.code, nullptr, nullptr, nullptr, nullptr,
                               status, s, lay))
       return e;
+    if (params->normalizer == RH_NORM_GLOBAL)
+      if (int e = launch_count(w, batch, num_pos, s)) return e;
   }
   if (stages & RH_STAGE_STREAM) {
     auto kern = params->from_logits ? focal_levels_kernel<true> : focal_levels_kernel<false>;
     hipLaunchKernelGGL(kern, dim3(lp.chunks, csplit, batch), dim3(kLvlThreads), 0, s, lt,
                        reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
                        w.partials, (int)lp.n, anchors_per_cell, num_classes, m, fc,
-                       params->grad_cls, params->grad_reg, divisor);
+                       params->grad_cls, params->grad_reg, divisor, nrm.total);
     RH_CHECK_LAUNCH("focal_levels_kernel");
   }
   if (stages & RH_STAGE_FINALIZE) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
                        w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)lp.n, 0,
-                       (int)blocks, divisor);
+                       (int)blocks, divisor, nrm.total);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;

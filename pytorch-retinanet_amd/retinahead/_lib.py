@@ -42,7 +42,13 @@ class FocalParams(C.Structure):
         ("grad_reg", C.c_float),
         ("batch_divisor", C.c_int32),
         ("from_logits", C.c_int32),
+        ("normalizer", C.c_int32),
+        ("num_pos_total", C.c_void_p),
     ]
+
+
+NORM_PER_IMAGE, NORM_GLOBAL = 0, 1
+NORMALIZERS = {"per_image": NORM_PER_IMAGE, "global": NORM_GLOBAL}
 
 
 class PostParams(C.Structure):

@@ -8,8 +8,15 @@ a 4-float vector (classification loss, regression loss, number of positive ancho
 number of images) over RCCL/xGMI yields the global losses and the global counts.
 Gradients with respect to the predictions need no exchange.  The reference's own multi-GPU mechanism is
 nn.DataParallel (train.py:137).
+
+With ``FocalLoss(normalizer='global')`` the normaliser itself is global: each rank runs the
+assignment stage, ONE more all-reduce sums the positive counts over all ranks before the
+streaming stage scales losses and gradients by it, and the ranks' losses are then shares that the
+loss all-reduce adds up.
 """
 from __future__ import annotations
+
+import functools
 
 import torch
 import torch.distributed as dist_
@@ -35,6 +42,15 @@ def all_reduce_losses(local_losses, group=None):
     return local_losses + (total - local_losses.detach())
 
 
+def all_reduce_num_pos(num_pos, group=None):
+    """float32 [1]: positives over all ranks from this rank's per-image counts (exact below
+    2^24)."""
+    total = num_pos.sum(dtype=torch.float32).reshape(1)
+    if dist_.is_available() and dist_.is_initialized() and dist_.get_world_size(group) > 1:
+        dist_.all_reduce(total, op=dist_.ReduceOp.SUM, group=group)
+    return total
+
+
 class DataParallelFocalLoss(torch.nn.Module):
     """Wraps a loss callable with the FocalLoss signature for sharded batches.
 
@@ -47,6 +63,9 @@ class DataParallelFocalLoss(torch.nn.Module):
         super().__init__()
         self.loss_fn = loss_fn
         self.group = group
+        cfg = getattr(loss_fn, "cfg", None)
+        if isinstance(cfg, dict) and cfg.get("normalizer") == "global":
+            cfg["reduce_total"] = functools.partial(all_reduce_num_pos, group=group)
 
     def forward(self, classifications, regressions, anchors, annotations):
         out = self.loss_fn(classifications, regressions, anchors, annotations)

@@ -191,13 +191,33 @@ def assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5):
 _ws_bytes_cache = {}
 
 
+def _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor, from_logits,
+                  normalizer, num_pos_total, dev):
+    try:
+        norm = _lib.NORMALIZERS[normalizer]
+    except KeyError:
+        raise ValueError("normalizer must be 'per_image' or 'global'") from None
+    total = None
+    if num_pos_total is not None:
+        if (num_pos_total.device != dev or num_pos_total.dtype != torch.float32
+                or num_pos_total.numel() != 1):
+            raise RetinaHeadError("num_pos_total must be one float32 on the inputs' device")
+        total = num_pos_total.data_ptr()
+    return _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
+                            float(grad_reg), int(batch_divisor), int(bool(from_logits)), norm, total)
+
+
 def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alpha=0.25,
                        neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
-                       batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False):
+                       batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False,
+                       normalizer="per_image", num_pos_total=None):
     """Runs the fused loss kernels.  Returns a dict of device tensors:
     losses [2], total [1] (their sum; adjacent in memory), per_image [2,B], num_pos [B], status [B],
     d_classifications, d_regressions.
     ``out`` may carry buffers from an earlier call (used when stages are run one at a time).
+    ``normalizer='global'``: one positive count for the whole batch instead of the reference's
+    per-image counts and batch mean; ``num_pos_total`` (device float32 [1]) supplies a count
+    formed elsewhere (over all ranks of a data-parallel job), else the call counts its own.
     """
     dev = _dev_check(classifications, regressions, anchors_t, annotations)
     cls, reg = _f32c(classifications), _f32c(regressions)
@@ -223,8 +243,8 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
             d_classifications=torch.empty_like(cls),
             d_regressions=torch.empty_like(reg),
         )
-    params = _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
-                              float(grad_reg), int(batch_divisor), int(bool(from_logits)))
+    params = _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor,
+                           from_logits, normalizer, num_pos_total, dev)
     shape_key = (bsz, n, c, m)
     need = _ws_bytes_cache.get(shape_key)
     if need is None:
@@ -242,7 +262,8 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
 
 def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, alpha=0.25,
                               neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
-                              batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False):
+                              batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False,
+                              normalizer="per_image", num_pos_total=None):
     """The fused loss on the heads' own outputs: ``cls_levels[l]`` is [B, A*C, H_l, W_l] and
     ``reg_levels[l]`` is [B, A*4, H_l, W_l], the tensors the reference permutes, reshapes and
     concatenates into [B,N,C] / [B,N,4] (models/retinanet/model.py:152-154,196-202,311-313).
@@ -295,8 +316,8 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
             d_cls_all=d_cls_all, d_reg_all=d_reg_all,
             d_cls_levels=views(d_cls_all, cls), d_reg_levels=views(d_reg_all, reg),
         )
-    params = _lib.FocalParams(float(alpha), float(neg_thresh), float(pos_thresh), float(grad_cls),
-                              float(grad_reg), int(batch_divisor), int(bool(from_logits)))
+    params = _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor,
+                           from_logits, normalizer, num_pos_total, dev)
     ptrs = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
     ints = lambda vs: (C.c_int32 * nl)(*vs)
     h_arr, w_arr = ints(hs), ints(wsz)

@@ -71,17 +71,32 @@ def _upstream(g_part, g_total):
     return g_part if g_total is None else g_part + g_total
 
 
+def _run_fused(fn, tensors, cfg):
+    """Calls a fused-loss wrapper with the module's settings.  With the batch-wide normaliser
+    and a ``reduce_total`` hook (data-parallel use) the assignment stage runs first, the hook
+    turns the shard's positive counts into the count over all ranks, and the remaining stages
+    normalise by that."""
+    kw = dict(alpha=cfg["alpha"], neg_thresh=cfg["neg_thresh"], pos_thresh=cfg["pos_thresh"],
+              grad_cls=cfg["expected_grad"], grad_reg=cfg["expected_grad"],
+              batch_divisor=cfg["batch_divisor"], from_logits=cfg["from_logits"],
+              normalizer=cfg["normalizer"])
+    hook = cfg.get("reduce_total")
+    if cfg["normalizer"] == "global" and hook is not None:
+        out = fn(*tensors, stages=_lib.STAGE_ASSIGN, **kw)
+        total = hook(out["num_pos"])
+        return fn(*tensors, stages=_lib.STAGE_STREAM | _lib.STAGE_FINALIZE, out=out,
+                  num_pos_total=total, **kw)
+    return fn(*tensors, **kw)
+
+
 class _DenseHeadLossFn(torch.autograd.Function):
     """Forward launches the fused forward+backward kernels and keeps the gradients;
     backward applies the upstream gradients to them in place (one launch, no host read)."""
 
     @staticmethod
     def forward(ctx, classifications, regressions, anchors, annotations, cfg):
-        out = F.focal_loss_fwd_bwd(
-            classifications, regressions, anchors, annotations, alpha=cfg["alpha"],
-            neg_thresh=cfg["neg_thresh"], pos_thresh=cfg["pos_thresh"],
-            grad_cls=cfg["expected_grad"], grad_reg=cfg["expected_grad"],
-            batch_divisor=cfg["batch_divisor"], from_logits=cfg["from_logits"])
+        out = _run_fused(F.focal_loss_fwd_bwd,
+                         (classifications, regressions, anchors, annotations), cfg)
         ctx.d_cls = out["d_classifications"]
         ctx.d_reg = out["d_regressions"]
         ctx.expected = cfg["expected_grad"]
@@ -115,11 +130,8 @@ class _DenseHeadLevelsLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, anchors, annotations, num_levels, *levels):
         cls_levels, reg_levels = levels[:num_levels], levels[num_levels:]
-        out = F.focal_loss_levels_fwd_bwd(
-            cls_levels, reg_levels, anchors, annotations, alpha=cfg["alpha"],
-            neg_thresh=cfg["neg_thresh"], pos_thresh=cfg["pos_thresh"],
-            grad_cls=cfg["expected_grad"], grad_reg=cfg["expected_grad"],
-            batch_divisor=cfg["batch_divisor"], from_logits=cfg["from_logits"])
+        out = _run_fused(F.focal_loss_levels_fwd_bwd,
+                         (cls_levels, reg_levels, anchors, annotations), cfg)
         ctx.flat = (out["d_cls_all"], out["d_reg_all"])
         ctx.grads = (out["d_cls_levels"], out["d_reg_levels"])
         ctx.expected = cfg["expected_grad"]
@@ -167,14 +179,22 @@ class FocalLoss(nn.Module):
         kernel (same loss; the gradient is the one autograd gives through
         ``torch.sigmoid``), which saves the head a full read and write of the [B,N,C]
         tensor in each direction.
+    normalizer: 'per_image' is the reference (each image's sums divided by its own positive
+        count, losses.py:94 and :134, then the batch mean, :139-141).  'global' divides the
+        batch's sums by the positive count of the whole batch instead (no batch mean;
+        ``batch_divisor`` unused); under ``retinahead.dist.DataParallelFocalLoss`` that count
+        runs over all ranks.  Both agree when every image has the same number of positives.
     """
 
     def __init__(self, alpha=0.25, neg_thresh=0.4, pos_thresh=0.5, expected_grad=1.0,
-                 batch_divisor=0, check_labels=False, from_logits=False):
+                 batch_divisor=0, check_labels=False, from_logits=False, normalizer="per_image"):
         super().__init__()
+        if normalizer not in _lib.NORMALIZERS:
+            raise ValueError("normalizer must be 'per_image' or 'global'")
         self.cfg = dict(alpha=float(alpha), neg_thresh=float(neg_thresh),
                         pos_thresh=float(pos_thresh), expected_grad=float(expected_grad),
-                        batch_divisor=int(batch_divisor), from_logits=bool(from_logits), last=None)
+                        batch_divisor=int(batch_divisor), from_logits=bool(from_logits),
+                        normalizer=normalizer, reduce_total=None, last=None)
         self.check_labels = bool(check_labels)
 
     @property

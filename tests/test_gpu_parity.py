@@ -324,6 +324,98 @@ def test_loss_batch_divisor_and_expected_grad(rh):
     grad_close(np.concatenate([p[2] for p in parts]), ref["d_regressions"], atol_rel=REG_ATOL_REL)
 
 
+@pytest.mark.parametrize("bsz,size,c,m,valid", [
+    (3, 256, 80, 8, [8, 0, 3]),      # tile kernel, an empty image
+    (2, 96, 5, 4, [4, 1]),           # C not a multiple of 4
+    (1, 64, 3, 4, [3]),              # generic row kernel
+])
+def test_global_normaliser_vs_oracle(rh, bsz, size, c, m, valid):
+    """normalizer='global' (one positive count for the batch; not in the reference, so pinned to the
+    oracle's restatement, which the CPU suite ties to the reference-checked per-image mode)."""
+    cls, reg, anc, ann = make_batch(11 + c, bsz, size, c, m, valid)
+    ref = O.focal_loss_fwd_bwd(cls, reg, anc, ann, normalizer="global")
+    out = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann), normalizer="global")
+    assert np.array_equal(out["num_pos"].cpu().numpy(), ref["num_pos"])
+    assert np.allclose(out["losses"].cpu().numpy(),
+                       [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
+    assert out["total"].item() == (out["losses"][0] + out["losses"][1]).item()
+    pi = out["per_image"].cpu().numpy()
+    assert np.allclose(pi[0], ref["cls_per_image"], rtol=RTOL, atol=0)
+    assert np.allclose(pi[1], ref["reg_per_image"], rtol=RTOL, atol=0)
+    grad_close(out["d_classifications"].cpu().numpy(), ref["d_classifications"])
+    grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+    # a count formed elsewhere (all ranks of a data-parallel job): stages run apart, as the module does
+    from retinahead import _lib
+    total = torch.tensor([2.0 * float(ref["num_pos"].sum()) + 3.0], device="cuda")
+    ref2 = O.focal_loss_fwd_bwd(cls, reg, anc, ann, normalizer="global", num_pos_total=int(total.item()))
+    args = (dev(cls), dev(reg), dev(anc), dev(ann))
+    st = rh.functional.focal_loss_fwd_bwd(*args, normalizer="global", stages=_lib.STAGE_ASSIGN)
+    assert np.array_equal(st["num_pos"].cpu().numpy(), ref["num_pos"])      # counted in the assign stage
+    st = rh.functional.focal_loss_fwd_bwd(*args, normalizer="global", num_pos_total=total, out=st,
+                                          stages=_lib.STAGE_STREAM | _lib.STAGE_FINALIZE)
+    assert np.allclose(st["losses"].cpu().numpy(),
+                       [ref2["classification_loss"][0], ref2["regression_loss"][0]], rtol=RTOL, atol=0)
+    grad_close(st["d_classifications"].cpu().numpy(), ref2["d_classifications"])
+    grad_close(st["d_regressions"].cpu().numpy(), ref2["d_regressions"], atol_rel=REG_ATOL_REL)
+    with pytest.raises(rh.RetinaHeadError):
+        rh.functional.focal_loss_fwd_bwd(*args, num_pos_total=total)          # per-image mode takes none
+
+
+def test_global_normaliser_module_and_head_layout(rh):
+    """The module with the data-parallel hook (world of one: the hook only sums the shard's counts)
+    equals the unhooked call, on the flat and on the head layout; equal positive counts in every
+    image make the mode coincide with the reference's per-image normaliser."""
+    from retinahead import dist as rdist
+    rng = np.random.default_rng(77)
+    h = w = 128
+    c, a, bsz = 6, 9, 3
+    anc = O.anchors_for_image(h, w)
+    shapes = [((h + 2 ** l - 1) // 2 ** l, (w + 2 ** l - 1) // 2 ** l) for l in (3, 4, 5, 6, 7)]
+    cls_lv = [rng.uniform(0.001, 0.4, (bsz, a * c, y, x)).astype(np.float32) for (y, x) in shapes]
+    reg_lv = [rng.normal(0, 1, (bsz, a * 4, y, x)).astype(np.float32) for (y, x) in shapes]
+    _, _, _, ann = make_batch(78, bsz, h, c, 5, [5, 1, 3])
+    cls_flat, reg_flat = flat_from_levels(cls_lv, a, c), flat_from_levels(reg_lv, a, 4)
+    ref = O.focal_loss_fwd_bwd(cls_flat, reg_flat, anc, ann, normalizer="global")
+    assert len(set(ref["num_pos"].tolist())) > 1
+
+    results = []
+    for hooked in (False, True):
+        mod = rh.FocalLoss(normalizer="global")
+        if hooked:
+            rdist.DataParallelFocalLoss(mod)          # installs reduce_total
+            assert mod.cfg["reduce_total"] is not None
+        tc, tr = dev(cls_flat).requires_grad_(True), dev(reg_flat).requires_grad_(True)
+        out = mod(tc, tr, dev(anc), dev(ann))
+        sum(out.values()).backward()
+        lc = [dev(t).requires_grad_(True) for t in cls_lv]
+        lr = [dev(t).requires_grad_(True) for t in reg_lv]
+        out_lv = mod.forward_levels(lc, lr, dev(anc), dev(ann))
+        sum(out_lv.values()).backward()
+        results.append((out, tc.grad, tr.grad, out_lv, lc, lr))
+        for o in (out, out_lv):
+            assert np.isclose(o["classification_loss"].item(), ref["classification_loss"][0], rtol=RTOL)
+            assert np.isclose(o["regression_loss"].item(), ref["regression_loss"][0], rtol=RTOL)
+        grad_close(tc.grad.cpu().numpy(), ref["d_classifications"])
+        grad_close(tr.grad.cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+        want_c = levels_from_flat(tc.grad.cpu().numpy(), shapes, a, c)
+        want_r = levels_from_flat(tr.grad.cpu().numpy(), shapes, a, 4)
+        for l in range(len(shapes)):
+            assert np.array_equal(lc[l].grad.cpu().numpy(), want_c[l]), l
+            assert np.array_equal(lr[l].grad.cpu().numpy(), want_r[l]), l
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+    assert results[0][0]["classification_loss"].item() == results[1][0]["classification_loss"].item()
+
+    # every image with the same annotations -> same positive counts -> both normalisers agree
+    same = np.repeat(ann[:1], bsz, axis=0)
+    args = (dev(cls_flat), dev(reg_flat), dev(anc), dev(same))
+    per = rh.functional.focal_loss_fwd_bwd(*args)
+    glo = rh.functional.focal_loss_fwd_bwd(*args, normalizer="global")
+    assert int(per["num_pos"][0]) > 0 and len(set(per["num_pos"].tolist())) == 1
+    assert torch.allclose(per["losses"], glo["losses"], rtol=1e-6, atol=0)
+    assert torch.allclose(per["d_classifications"], glo["d_classifications"], rtol=1e-6, atol=0)
+    assert torch.allclose(per["d_regressions"], glo["d_regressions"], rtol=1e-6, atol=0)
+
+
 def test_label_out_of_range_flag(rh):
     cls, reg, anc, ann = make_batch(9, 1, 64, 4, 3, [3])
     ann[0, 1, 4] = 4.0                                   # == C: IndexError in the reference

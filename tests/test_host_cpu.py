@@ -162,7 +162,7 @@ def _free_port():
     return port
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, normalizer="per_image"):
     import torch.distributed as dist
     for p in (ROOT, PKG_DIR):
         if p not in sys.path:
@@ -177,8 +177,13 @@ def _dp_worker(rank, world, port, q):
     lo, hi = rdist.shard_bounds(bsz, rank, world)
 
     def local_loss(c, r, a, an):     # the oracle stands in for the HIP kernels on this GPU-less host
+        kw = {}
+        if normalizer == "global":   # the staged call of the module: assign, exchange, stream
+            counts = [O.assign(a.numpy().reshape(-1, 4), row)["num_pos"] for row in an.numpy()]
+            total = local_loss.cfg["reduce_total"](torch.tensor(counts, dtype=torch.int32))
+            kw = dict(normalizer="global", num_pos_total=int(total.item()))
         o = O.focal_loss_fwd_bwd(c.detach().numpy(), r.detach().numpy(), a.numpy(), an.numpy(),
-                                 batch_divisor=bsz)
+                                 batch_divisor=bsz, **kw)
 
         class Fn(torch.autograd.Function):
             @staticmethod
@@ -195,7 +200,9 @@ def _dp_worker(rank, world, port, q):
 
     c = torch.from_numpy(cls[lo:hi]).clone().requires_grad_(True)
     r = torch.from_numpy(reg[lo:hi]).clone().requires_grad_(True)
+    local_loss.cfg = dict(normalizer=normalizer, reduce_total=None)
     mod = rdist.DataParallelFocalLoss(local_loss)
+    assert (local_loss.cfg["reduce_total"] is not None) == (normalizer == "global")
     out = mod(c, r, torch.from_numpy(anc), torch.from_numpy(ann[lo:hi]))
     (out["classification_loss"] + out["regression_loss"]).sum().backward()
     q.put((rank, lo, hi, out["classification_loss"].item(), out["regression_loss"].item(),
@@ -230,3 +237,29 @@ def test_data_parallel_equals_single_process(world):
     full_r = np.concatenate([t[6] for t in res]) * gscale[1]
     assert np.allclose(full_c, g["normal.d_cls"], rtol=1e-5, atol=1e-12)
     assert np.allclose(full_r, g["normal.d_reg"], rtol=1e-5, atol=1e-9)
+
+
+def test_data_parallel_global_normaliser():
+    """normalizer='global' over 2 ranks: one more all-reduce (the positive count) and the ranks'
+    losses are shares; the result is the single-process batch-wide result.  (The reference has no
+    such mode: the single-process side is the oracle's restatement, parity unpinned.)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, "global")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("focal_loss.npz")
+    cls, reg, anc, ann = (g["normal." + k] for k in ("cls", "reg", "anchors", "ann"))
+    want = O.focal_loss_fwd_bwd(cls, reg, anc, ann, normalizer="global")
+    for rank, lo, hi, cl, rl, gc, gr in res:
+        assert np.isclose(cl, want["classification_loss"][0], rtol=1e-5)
+        assert np.isclose(rl, want["regression_loss"][0], rtol=1e-5)
+    assert np.allclose(np.concatenate([t[5] for t in res]), want["d_classifications"], rtol=1e-5,
+                       atol=1e-12)
+    assert np.allclose(np.concatenate([t[6] for t in res]), want["d_regressions"], rtol=1e-5, atol=1e-9)

@@ -137,3 +137,32 @@ def test_detection_evaluation_matches_reference():
                                         score_threshold=0.05, max_detections=25)
         assert np.array_equal(num, g[tag + ".num_annotations"])
         assert np.allclose(ap, g[tag + ".ap"], rtol=1e-12, atol=0), (ap, g[tag + ".ap"])
+
+
+def test_global_normaliser_is_a_reweighting_of_the_reference_mode(focal_golden):
+    """normalizer='global' has no counterpart in the reference (parity unpinned); it is pinned to
+    the reference-checked per-image mode instead: image j's loss and gradients are the per-image
+    ones times max(num_pos_j, 1) * B / max(P, 1) (classification) and num_pos_j * B / P
+    (regression), P = all positives of the batch."""
+    g = focal_golden["normal"]
+    cls, reg, anc, ann = (g[k] for k in ("cls", "reg", "anchors", "ann"))
+    per = O.focal_loss_fwd_bwd(cls, reg, anc, ann)
+    glo = O.focal_loss_fwd_bwd(cls, reg, anc, ann, normalizer="global")
+    npos = per["num_pos"].astype(np.float64)
+    assert np.array_equal(per["num_pos"], glo["num_pos"])
+    bsz, total = len(npos), npos.sum()
+    assert total > 0 and len(set(npos.tolist())) > 1        # the modes differ on this fixture
+    wc = np.maximum(npos, 1) / max(total, 1)
+    wr = npos / total
+    assert np.allclose(glo["cls_per_image"], per["cls_per_image"] * wc, rtol=1e-6)
+    assert np.allclose(glo["reg_per_image"], per["reg_per_image"] * wr, rtol=1e-6)
+    assert np.isclose(glo["classification_loss"][0], (per["cls_per_image"] * wc).sum(), rtol=1e-6)
+    assert np.isclose(glo["regression_loss"][0], (per["reg_per_image"] * wr).sum(), rtol=1e-6)
+    assert np.allclose(glo["d_classifications"],
+                       per["d_classifications"] * (wc * bsz)[:, None, None], rtol=1e-5, atol=1e-30)
+    assert np.allclose(glo["d_regressions"],
+                       per["d_regressions"] * (wr * bsz)[:, None, None], rtol=1e-5, atol=1e-30)
+    # a count supplied from outside (all ranks of a data-parallel job) replaces the batch's own
+    twice = O.focal_loss_fwd_bwd(cls, reg, anc, ann, normalizer="global", num_pos_total=2 * int(total))
+    assert np.isclose(twice["classification_loss"][0] * 2, glo["classification_loss"][0], rtol=1e-6)
+    assert np.allclose(twice["d_regressions"] * 2, glo["d_regressions"], rtol=1e-6, atol=1e-30)
