@@ -41,8 +41,11 @@ class _LossTensor(torch.Tensor):
             if isinstance(b, _LossTensor) and _is_zero(a):
                 return b
             if isinstance(a, _LossTensor) and isinstance(b, _LossTensor) and a is not b \
-                    and a._token is not None and a._token is b._token:
-                return a._total
+                    and a._total is not None and a._token is b._token:
+                # handed out once: train.py:187 divides the sum in place, and a second sum of
+                # the same dict must not see that
+                total, a._total, b._total = a._total, None, None
+                return total
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         return out.as_subclass(torch.Tensor) if isinstance(out, _LossTensor) else out
@@ -62,6 +65,17 @@ def _as_loss_dict(cls_loss, reg_loss, total):
     c._token = r._token = object()
     c._total = r._total = total
     return {"classification_loss": c, "regression_loss": r}
+
+
+def _loss_outputs(out):
+    """The three [1] outputs of the autograd node on the call's small buffer.  They share its
+    storage without being views of it: autograd refuses in-place operations on views returned by
+    a node with several outputs, and train.py:187 (``loss /= iterations``) is one."""
+    losses, total = out["losses"], out["total"]
+    store = losses.untyped_storage()
+    at = losses.storage_offset()
+    return (losses.new_empty(0).set_(store, at, (1,)), losses.new_empty(0).set_(store, at + 1, (1,)),
+            losses.new_empty(0).set_(store, total.storage_offset(), (1,)))
 
 
 def _upstream(g_part, g_total):
@@ -105,8 +119,7 @@ class _DenseHeadLossFn(torch.autograd.Function):
         # autograd's AccumulateGrad copy them (hundreds of MB) instead of adopting them
         cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
         ctx.set_materialize_grads(False)
-        losses = out["losses"]          # fresh storage every call: views need no copy
-        return losses[0:1], losses[1:2], out["total"]
+        return _loss_outputs(out)       # fresh storage every call: no copy needed
 
     @staticmethod
     def backward(ctx, g_cls, g_reg, g_total):
@@ -138,8 +151,7 @@ class _DenseHeadLevelsLossFn(torch.autograd.Function):
         ctx.in_dtypes = [t.dtype for t in levels]
         cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
         ctx.set_materialize_grads(False)
-        losses = out["losses"]
-        return losses[0:1], losses[1:2], out["total"]
+        return _loss_outputs(out)
 
     @staticmethod
     def backward(ctx, g_cls, g_reg, g_total):

@@ -258,7 +258,9 @@ def test_loss_sum_uses_the_stored_total(rh, focal_golden):
             loss = sum(l for l in out.values())
             assert type(loss) is torch.Tensor and loss.shape == (1,)
             assert loss.item() == (c.detach().clone() + r.detach().clone()).item()
-            assert sum(out.values()).data_ptr() == loss.data_ptr()       # the stored total, no new tensor
+            assert loss.data_ptr() == c.data_ptr() + 8                   # the stored total, no new tensor
+            again = sum(out.values())                                    # handed out once: a new tensor
+            assert again.data_ptr() != loss.data_ptr() and again.item() == loss.item()
         elif how == "plain_add":
             loss = c + r
         elif how == "scaled":
@@ -280,12 +282,30 @@ def test_loss_sum_uses_the_stored_total(rh, focal_golden):
     (sum(out.values()) + out["classification_loss"]).sum().backward()
     assert torch.allclose(cls.grad, 2 * grads[0][0], rtol=1e-6, atol=0)
     assert torch.equal(reg.grad, grads[0][1])
-    # gradient accumulation, train.py:187-190
+    # gradient accumulation, train.py:185-190 word for word: the sum is divided IN PLACE
+    for expected in (0.25, 1.0):
+        cls = dev(d["cls"]).requires_grad_(True)
+        reg = dev(d["reg"]).requires_grad_(True)
+        loss_dict = rh.FocalLoss(expected_grad=expected)(cls, reg, *args)
+        loss = sum(loss for loss in loss_dict.values())
+        monitor_loss = loss.clone().detach()
+        loss /= 4
+        assert np.isclose(float(loss.item()) * 4, float(monitor_loss.item()), rtol=1e-6)
+        loss.backward()
+        assert torch.allclose(cls.grad, grads[0][0] / 4, rtol=1e-6, atol=0)
+        assert torch.allclose(reg.grad, grads[0][1] / 4, rtol=1e-6, atol=0)
+        # the dict still holds the undivided losses (train.py:193-197 logs them)
+        assert np.isclose(sum(float(v) for v in loss_dict.values()), float(monitor_loss), rtol=1e-6)
+        assert np.isclose(float(sum(loss_dict.values())), float(monitor_loss), rtol=1e-6)
+    # in-place operations on the individual losses work as on any tensor
     cls = dev(d["cls"]).requires_grad_(True)
     reg = dev(d["reg"]).requires_grad_(True)
-    out = rh.FocalLoss(expected_grad=0.25)(cls, reg, *args)
-    (sum(out.values()) / 4).backward()
-    assert torch.allclose(cls.grad, grads[0][0] / 4, rtol=1e-6, atol=0)
+    out = rh.FocalLoss()(cls, reg, *args)
+    c = out["classification_loss"]
+    c *= 2
+    (c + out["regression_loss"]).backward()
+    assert torch.allclose(cls.grad, 2 * grads[0][0], rtol=1e-6, atol=0)
+    assert torch.equal(reg.grad, grads[0][1])
 
 
 def test_loss_deterministic_and_unaligned(rh):
