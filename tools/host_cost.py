@@ -75,3 +75,11 @@ for _ in range(200):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(200):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(12)
