@@ -256,7 +256,7 @@ def test_loss_sum_uses_the_stored_total(rh, focal_golden):
         assert c.shape == (1,) and r.shape == (1,) and c.grad_fn is not None
         if how == "sum":
             loss = sum(l for l in out.values())
-            assert type(loss) is torch.Tensor and loss.shape == (1,)
+            assert isinstance(loss, torch.Tensor) and loss.shape == (1,)
             assert loss.item() == (c.detach().clone() + r.detach().clone()).item()
             assert loss.data_ptr() == c.data_ptr() + 8                   # the stored total, no new tensor
             again = sum(out.values())                                    # handed out once: a new tensor
@@ -342,6 +342,48 @@ def test_loss_batch_divisor_and_expected_grad(rh):
     assert np.isclose(rl, ref["regression_loss"][0], rtol=RTOL)
     grad_close(np.concatenate([p[1] for p in parts]), ref["d_classifications"])
     grad_close(np.concatenate([p[2] for p in parts]), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+
+
+def test_plain_backward_launches_nothing_more(rh, focal_golden, monkeypatch):
+    """loss.backward() on the summed loss (train.py:185, 190) with the default expected gradient:
+    the stored gradients are final, so the backward pass runs no scaling launch; every other way of
+    reaching the node still scales (or zeroes) them."""
+    d = focal_golden["normal"]
+    args = (dev(d["anchors"]), dev(d["ann"]))
+    calls = []
+    real = rh.functional.apply_upstream
+    monkeypatch.setattr(rh.functional, "apply_upstream", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(how, **kw):
+        cls = dev(d["cls"]).requires_grad_(True)
+        reg = dev(d["reg"]).requires_grad_(True)
+        out = rh.FocalLoss(**kw)(cls, reg, *args)
+        del calls[:]
+        how(out)
+        return cls.grad, reg.grad, len(calls)
+
+    gc, gr, n = run(lambda o: sum(o.values()).backward())
+    assert n == 0
+    grad_close(gc.cpu().numpy(), d["d_cls"] / d["g"][0])
+    grad_close(gr.cpu().numpy(), d["d_reg"] / d["g"][1], atol_rel=REG_ATOL_REL)
+    gc2, gr2, n = run(lambda o: (o["classification_loss"] + o["regression_loss"]).backward())
+    assert n == 0 and torch.equal(gc, gc2) and torch.equal(gr, gr2)
+    # an explicit gradient, a scaled loss, one loss alone, another expected gradient: all scale
+    gc2, gr2, n = run(lambda o: sum(o.values()).backward(torch.full((1,), 2.0, device="cuda")))
+    assert n == 1 and torch.allclose(gc2, 2 * gc, rtol=1e-6, atol=0)
+    gc2, gr2, n = run(lambda o: (sum(o.values()) * 3).backward())
+    assert n == 1 and torch.allclose(gr2, 3 * gr, rtol=1e-6, atol=0)
+    gc2, gr2, n = run(lambda o: o["classification_loss"].backward())
+    assert n == 1 and torch.equal(gc2, gc) and int((gr2 != 0).sum()) == 0
+    gc2, gr2, n = run(lambda o: sum(o.values()).backward(), expected_grad=0.5)
+    assert n == 1 and torch.allclose(gc2, gc, rtol=1e-6, atol=0)
+    # retain_graph is passed through; the node itself still serves one backward per forward
+    cls = dev(d["cls"]).requires_grad_(True)
+    out = rh.FocalLoss()(cls, dev(d["reg"]), *args)
+    loss = sum(out.values())
+    loss.backward(retain_graph=True)
+    with pytest.raises(rh.RetinaHeadError):
+        loss.backward()
 
 
 @pytest.mark.parametrize("bsz,size,c,m,valid", [
