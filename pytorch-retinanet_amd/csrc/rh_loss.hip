@@ -33,7 +33,6 @@ constexpr int kNoLabel = 0xFFFF;
 
 constexpr int kTileRows = 64;      // anchors per stream tile
 constexpr int kThreads = 256;
-constexpr int kGtChunk = 256;      // GT boxes staged in LDS at a time
 constexpr int kGenericBlocks = 64; // blocks per image of the generic row kernel
 
 // ---------------------------------------------------------------------------
@@ -55,20 +54,26 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 // ---------------------------------------------------------------------------
 // Assignment, one launch: GT filter + IoU + max / first arg-max + thresholds + labels.
 //
-// Every block compacts its image's annotation rows itself (rows with label != -1, in order,
-// losses.py:48-49; areas losses.py:7; labels truncated like .long(), losses.py:79), 256 rows
-// at a time into LDS, and scans them for its anchors: kAssignPer anchors per thread (strided
-// by the block size, so loads and stores stay coalesced), GT boxes read as wave-uniform
-// broadcasts.  Block 0 of each image also publishes the compacted records, the valid count
-// and the status word for the kernels that follow.  Positives are counted per block into
-// blk_pos[image][block]: no atomics and nothing to zero beforehand.
+// A wave works on its own: no LDS staging, no barriers before the final count.  Lane r holds
+// annotation row r of the image (64 rows at a time); rows with label != -1 are the valid GT
+// boxes, in order (losses.py:48-49; areas losses.py:7; labels truncated like .long(),
+// losses.py:79).  The wave first forms the bounding box of all its anchors (consecutive
+// anchors lie in neighbouring cells, so on the fine pyramid levels the box is small): a GT box
+// that does not reach into it has an empty intersection with every anchor of the wave -- for
+// each one min(ax2, bx2) - max(ax1, bx1) <= 0 or the same in y, exactly, in float32 -- so its
+// IoU is 0 and it can neither raise the maximum nor move the first arg-max.  One ballot over
+// the rows therefore leaves the few boxes the wave has to look at; they are broadcast from
+// their lanes one at a time and compared with kAssignPer anchors per thread (strided by the
+// block size, so loads and stores stay coalesced).  Most (anchor, GT) pairs never reach the
+// vector ALU.  Wave 0 of block 0 of each image also publishes the compacted records, the valid
+// count and the status word for the kernels that follow.  Positives are counted per block
+// into blk_pos[image][block]: no atomics and nothing to zero beforehand.
 // Max / first arg-max (losses.py:61), thresholds (:70-72), label lookup (:76-79), count (:74).
 // ---------------------------------------------------------------------------
-// Two anchors per thread.  Four were slower at both ends: with short annotation lists the
-// kernel is bound by its few dependent memory latencies and a coarser grid only unbalances it
-// (15.2 against 13.7 us at 16 x 69 354 anchors), and with 256 rows per image the grid gets too
-// small to hide the LDS and branch latencies of the pair loop (79 against 64 us at 4 x 196 416).
-constexpr int kAssignPer = 2;
+#ifndef RH_ASSIGN_PER
+#define RH_ASSIGN_PER 2
+#endif
+constexpr int kAssignPer = RH_ASSIGN_PER;   // anchors per thread
 constexpr int kAssignBlock = kThreads * kAssignPer;   // anchors per block
 static inline int assign_blocks(long long n) { return (int)((n + kAssignBlock - 1) / kAssignBlock); }
 
@@ -84,86 +89,138 @@ struct CodeLayout {
   int hw[kMaxLevels];
 };
 
+// Minimum / maximum over the wave, as a wave-uniform value: inclusive scan by DPP row shifts
+// (1, 2, 4, 8 lanes inside each row of 16), then the row broadcasts 15 -> rows 1, 3 and
+// 31 -> rows 2, 3; lane 63 ends up with the result.  Lanes without a source keep `ident`.
+template <bool kMax>
+__device__ __forceinline__ float wave_extreme(float v) {
+  const int ident = __float_as_int(kMax ? -__builtin_inff() : __builtin_inff());
+#define RH_DPP_STEP(ctrl, rows)                                                               \
+  {                                                                                           \
+    const float t = __int_as_float(                                                           \
+        __builtin_amdgcn_update_dpp(ident, __float_as_int(v), ctrl, rows, 0xf, false));       \
+    v = kMax ? vmax(v, t) : vmin(v, t);                                                       \
+  }
+  RH_DPP_STEP(0x111, 0xf)
+  RH_DPP_STEP(0x112, 0xf)
+  RH_DPP_STEP(0x114, 0xf)
+  RH_DPP_STEP(0x118, 0xf)
+  RH_DPP_STEP(0x142, 0xa)
+  RH_DPP_STEP(0x143, 0xc)
+#undef RH_DPP_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ float lane_value(const float v, const int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+struct AnnRow {
+  float x1, y1, x2, y2, lab;
+};
+__device__ __forceinline__ AnnRow load_row(const float* __restrict__ aj, const int m, const int M) {
+  const int mc = min(m, M - 1);       // clamped: all five values go out at once
+  AnnRow r;
+  r.x1 = aj[mc * 5 + 0];
+  r.y1 = aj[mc * 5 + 1];
+  r.x2 = aj[mc * 5 + 2];
+  r.y2 = aj[mc * 5 + 3];
+  r.lab = aj[mc * 5 + 4];
+  return r;
+}
+
+// Build-time diagnostic (-DRH_TIMELINE): thread 0 of every block stores wall-clock stamps at
+// the marked places; rh_dbg_read() copies them out.  Not part of the shipped library.
+#ifdef RH_TIMELINE
+__device__ long long rh_dbg[8 * 65536];
+#define RH_MARK(slot) do { if (threadIdx.x == 0) rh_dbg[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define RH_MARK(slot)
+#endif
 __global__ __launch_bounds__(kThreads) void assign_kernel(
     const float4* __restrict__ anchors, const float* __restrict__ ann, GtRec* __restrict__ gt,
     int* __restrict__ gt_count, int* __restrict__ status, int* __restrict__ code,
     unsigned char* __restrict__ state, int* __restrict__ argmax, int* __restrict__ label,
     float* __restrict__ iou_max, int* __restrict__ blk_pos, int N, int M, int C,
     float neg_thresh, float pos_thresh, CodeLayout lay) {
-  __shared__ float4 s_box[kGtChunk];
-  __shared__ float s_area[kGtChunk];
-  __shared__ int s_lab[kGtChunk];
   __shared__ int s_cnt[kThreads / 64];
+  RH_MARK(0);
 
-  const int j = blockIdx.y;
+  // Grid (image, block), blocks taken from the last one down: the blocks of the coarse pyramid
+  // levels, whose large anchors meet most GT boxes, are the long ones and start first, for
+  // every image at once.
+  const int j = blockIdx.x;
+  const int bx = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int base = blockIdx.x * kAssignBlock + threadIdx.x;
+  const int base = bx * kAssignBlock + threadIdx.x;
   const float* aj = ann + (size_t)j * M * 5;
-  const bool publisher = blockIdx.x == 0;
+  const bool publisher = bx == 0 && wave == 0;
 
   float4 a[kAssignPer];
   float area_a[kAssignPer], best[kAssignPer];
   int best_idx[kAssignPer], best_lab[kAssignPer];
 #pragma unroll
   for (int k = 0; k < kAssignPer; ++k) {
-    const int n = base + k * kThreads;
-    a[k] = n < N ? anchors[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // lanes past the last anchor repeat it: their results are not stored, and the wave's
+    // bounding box stays what the real anchors make it
+    a[k] = anchors[min(base + k * kThreads, N - 1)];
+  }
+  AnnRow next = M > 0 ? load_row(aj, lane, M) : AnnRow{0.f, 0.f, 0.f, 0.f, -1.0f};
+  float lo_x = a[0].x, lo_y = a[0].y, hi_x = a[0].z, hi_y = a[0].w;
+#pragma unroll
+  for (int k = 0; k < kAssignPer; ++k) {
     area_a[k] = (a[k].z - a[k].x) * (a[k].w - a[k].y);
     best[k] = 0.0f;   // every IoU is >= 0, so "first maximum" starts at (0, index 0)
     best_idx[k] = 0;
     best_lab[k] = -2; // "label of valid GT 0", resolved below if nothing beats IoU 0
+    if (k > 0) {
+      lo_x = vmin(lo_x, a[k].x);
+      lo_y = vmin(lo_y, a[k].y);
+      hi_x = vmax(hi_x, a[k].z);
+      hi_y = vmax(hi_y, a[k].w);
+    }
   }
+  const float ux1 = wave_extreme<false>(lo_x), uy1 = wave_extreme<false>(lo_y);
+  const float ux2 = wave_extreme<true>(hi_x), uy2 = wave_extreme<true>(hi_y);
 
+  RH_MARK(1);
   int cnt = 0;        // valid GT rows seen so far
   int bad = 0;
   int lab0 = -1;      // label of the image's first valid GT (arg-max of an all-zero IoU row)
-  for (int m0 = 0; m0 < M; m0 += kGtChunk) {
-    // ---- stage: one annotation row per thread, keep the valid ones, in order
-    // (all five values of the row are loaded up front, row index clamped: one memory latency
-    // instead of a label load followed by a dependent box load)
-    const int m = m0 + (int)threadIdx.x;
-    const int mc = min(m, M - 1);
-    const float rx1 = aj[mc * 5 + 0], ry1 = aj[mc * 5 + 1], rx2 = aj[mc * 5 + 2],
-                ry2 = aj[mc * 5 + 3], lab = aj[mc * 5 + 4];
-    const bool valid = m < M && lab != -1.0f;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const AnnRow r = next;
+    if (m0 + 64 < M) next = load_row(aj, m0 + 64 + lane, M);   // in flight during this chunk
+    const bool valid = m0 + lane < M && r.lab != -1.0f;
     const unsigned long long vm = __ballot(valid);
-    __syncthreads();                       // previous chunk's readers are done
-    if (lane == 0) s_cnt[wave] = __popcll(vm);
-    __syncthreads();
-    int slot = __popcll(vm & ((1ull << lane) - 1ull)), len = 0;
-#pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) {
-      slot += w < wave ? s_cnt[w] : 0;
-      len += s_cnt[w];
+    if (vm == 0ull) continue;
+    const float rarea = (r.x2 - r.x1) * (r.y2 - r.y1);
+    int li = (int)r.lab;
+    if (!(r.lab > -1.0f && r.lab < (float)C)) {   // also catches NaN
+      li = -1;
+      bad |= valid;
     }
-    if (valid) {
-      GtRec r;
-      r.x1 = rx1;
-      r.y1 = ry1;
-      r.x2 = rx2;
-      r.y2 = ry2;
-      r.area = (r.x2 - r.x1) * (r.y2 - r.y1);
-      int l = (int)lab;
-      if (!(lab > -1.0f && lab < (float)C)) {   // also catches NaN
-        l = -1;
-        bad = 1;
-      }
-      r.label = l;
-      r.pad0 = r.pad1 = 0;
-      s_box[slot] = make_float4(r.x1, r.y1, r.x2, r.y2);
-      s_area[slot] = r.area;
-      s_lab[slot] = l;
-      if (publisher) gt[(size_t)j * M + cnt + slot] = r;
+    const int before = __popcll(vm & ((1ull << lane) - 1ull));   // valid rows in lower lanes
+    if (publisher && valid) {
+      GtRec g;
+      g.x1 = r.x1;
+      g.y1 = r.y1;
+      g.x2 = r.x2;
+      g.y2 = r.y2;
+      g.area = rarea;
+      g.label = li;
+      g.pad0 = g.pad1 = 0;
+      gt[(size_t)j * M + cnt + before] = g;
     }
-    __syncthreads();
-    if (cnt == 0 && len > 0) lab0 = s_lab[0];
-    // ---- scan the chunk's valid boxes
-    // The box of the next iteration is read from LDS before the current one is used, so the
-    // LDS latency overlaps the arithmetic instead of opening every iteration.
-    float4 bn = s_box[0];
-    for (int i = 0; i < len; ++i) {
-      const float4 b = bn;
-      bn = s_box[min(i + 1, kGtChunk - 1)];
+    if (cnt == 0) lab0 = __builtin_amdgcn_readlane(li, __builtin_ctzll(vm));
+    // rows whose box reaches into the wave's bounding box; a NaN coordinate is never culled
+    const bool apart = (r.x2 <= ux1) | (r.x1 >= ux2) | (r.y2 <= uy1) | (r.y1 >= uy2);
+    unsigned long long hm = __ballot(valid & !apart);
+    while (hm) {
+      const int src = __builtin_ctzll(hm);
+      hm &= hm - 1ull;
+      const float4 b = make_float4(lane_value(r.x1, src), lane_value(r.y1, src),
+                                   lane_value(r.x2, src), lane_value(r.y2, src));
+      const int gi = cnt + __popcll(vm & ((1ull << src) - 1ull));
       // overlap test for the thread's anchors first; one (rare) branch per GT box
       float iw[kAssignPer], ih[kAssignPer], mm[kAssignPer];
 #pragma unroll
@@ -176,8 +233,8 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
 #pragma unroll
       for (int k = 1; k < kAssignPer; ++k) any = vmax(any, mm[k]);
       if (any > 0.0f) {
-        const float ab = s_area[i];
-        const int lb = s_lab[i];
+        const float ab = lane_value(rarea, src);
+        const int lb = __builtin_amdgcn_readlane(li, src);
 #pragma unroll
         for (int k = 0; k < kAssignPer; ++k) {
           if (mm[k] > 0.0f) {
@@ -191,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
               const float v = inter / ua;
               if (v > best[k]) {
                 best[k] = v;
-                best_idx[k] = cnt + i;
+                best_idx[k] = gi;
                 best_lab[k] = lb;
               }
             }
@@ -199,8 +256,9 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
         }
       }
     }
-    cnt += len;
+    cnt += __popcll(vm);
   }
+  RH_MARK(2);
 
   int npos = 0;
 #pragma unroll
@@ -242,20 +300,28 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
     }
   }
   npos = wave_sum(npos);
-  const int any_bad = __syncthreads_or(bad);   // also orders the s_cnt reuse below
   if (lane == 0) s_cnt[wave] = npos;
   __syncthreads();
   if (threadIdx.x == 0) {
     int t = 0;
 #pragma unroll
     for (int w = 0; w < kThreads / 64; ++w) t += s_cnt[w];
-    blk_pos[(size_t)j * gridDim.x + blockIdx.x] = t;
-    if (publisher) {
+    blk_pos[(size_t)j * gridDim.y + bx] = t;
+  }
+  if (publisher) {          // this wave has seen every row of the image
+    const bool any_bad = __ballot(bad != 0) != 0ull;
+    if (lane == 0) {
       gt_count[j] = cnt;
       if (status) status[j] = any_bad ? RH_STATUS_LABEL_RANGE : 0;
     }
   }
+  RH_MARK(3);
 }
+#ifdef RH_TIMELINE
+extern "C" int rh_dbg_read(long long* out, size_t count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rh_dbg), count * sizeof(long long));
+}
+#endif
 
 // Sum of an image's per-block positive counts; all threads of the block call it and get the
 // same value.  s_tmp: kThreads / 64 ints of LDS.
@@ -1066,7 +1132,9 @@ static int launch_assign(const float* anchors, const float* annotations, int bat
                          int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                          unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
                          hipStream_t s, const CodeLayout& lay = CodeLayout{}) {
-  dim3 grid((unsigned)w.nblk, (unsigned)batch);
+  RH_REQUIRE(w.nblk <= 65535, RH_ESHAPE, "n=%lld: at most %d anchors per image", n,
+             65535 * kAssignBlock);
+  dim3 grid((unsigned)batch, (unsigned)w.nblk);
   hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
                      reinterpret_cast<const float4*>(anchors), annotations, w.gt, w.gt_count, status,
                      code, state, argmax, label, iou_max, w.blk_pos, (int)n, m, c, neg_t, pos_t, lay);
