@@ -252,6 +252,11 @@ int rh_bbox_transform_f32(const float* boxes, const float* deltas, int32_t batch
                           const float* mean, const float* std, float* out, rh_stream_t stream);
 int rh_clip_boxes_f32(float* boxes, int64_t rows, float width, float height, rh_stream_t stream);
 
+/* out[i] = float32 sigmoid(x[i]), the classification head's output activation
+ * (models/retinanet/model.py:177, 193), bit for bit the probability the logits-in modes of
+ * rh_focal_loss_fwd_bwd and rh_postprocess derive from a logit.  x, out device [count]. */
+int rh_sigmoid_f32(const float* x, float* out, int64_t count, rh_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * NMS  -  replaces torchvision.ops.nms as called at model.py:336 (greedy, drop
  * when IoU > iou_threshold, ties in score keep the lower index first).
@@ -280,11 +285,6 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
  *   cand_count device i32 [B] or NULL, overflow device i32 [B] or NULL.
  *   out_cap = max_det if max_det > 0, else min(cand_cap, pre_nms_topk or cand_cap).
  * ------------------------------------------------------------------------- */
-/* out[i] = float32 sigmoid(x[i]), the classification head's output activation
- * (models/retinanet/model.py:177, 193), bit for bit the probability the logits-in modes of
- * rh_focal_loss_fwd_bwd and rh_postprocess derive from a logit.  x, out device [count]. */
-int rh_sigmoid_f32(const float* x, float* out, int64_t count, rh_stream_t stream);
-
 typedef struct rh_post_params {
   float height, width;   /* image size used by the clip (utils.py:134) */
   float score_thresh;    /* 0.05 model.py:325 */
