@@ -100,6 +100,49 @@ def test_assign_and_loss_golden(rh, focal_golden, case):
     grad_close(reg.grad.cpu().numpy(), d["d_reg"], atol_rel=REG_ATOL_REL)
 
 
+@pytest.mark.parametrize("m", [1, 63, 64, 65, 130, 300])
+def test_assign_ragged_annotation_rows(rh, m):
+    """Valid rows scattered among padding rows, lists longer than one 64-row chunk, chunks
+    without any valid row, boxes outside the image and degenerate boxes: states, arg-max (index
+    into the valid list), labels, IoU maxima and counts bit for bit."""
+    rng = np.random.default_rng(500 + m)
+    size, c, bsz = 160, 7, 4
+    anc = O.anchors_for_image(size, size)
+    ann = -np.ones((bsz, m, 5), np.float32)
+    for j in range(bsz):
+        keep = rng.random(m) < (0.0, 0.15, 0.6, 1.0)[j]          # image 0: no valid row at all
+        if j == 1 and m > 64:
+            keep[:64] = False                                     # a whole chunk of padding first
+            keep[64] = True
+        v = int(keep.sum())
+        x1, y1 = rng.uniform(-20, size, v), rng.uniform(-20, size, v)
+        w, h = np.exp(rng.uniform(np.log(4), np.log(size), v)), np.exp(rng.uniform(np.log(4), np.log(size), v))
+        rows = np.stack([x1, y1, x1 + w, y1 + h, rng.integers(0, c, v).astype(np.float64)], 1)
+        if v > 2:
+            rows[0, 2:4] = rows[0, 0:2]                           # zero-area box
+            rows[1, :4] = rows[2, :4]                             # duplicate: the first one wins ties
+        ann[j, keep] = rows.astype(np.float32)
+    asg = rh.functional.assign(dev(anc), dev(ann), c)
+    for j in range(bsz):
+        ref = O.assign(anc[0], ann[j])
+        assert int(asg["num_pos"][j]) == ref["num_pos"], j
+        assert np.array_equal(asg["state"][j].cpu().numpy(), ref["state"]), j
+        assert np.array_equal(asg["label"][j].cpu().numpy(), ref["label"]), j
+        if ref["num_gt"]:
+            assert np.array_equal(asg["argmax"][j].cpu().numpy(), ref["argmax"]), j
+            assert np.array_equal(asg["iou_max"][j].cpu().numpy(), ref["iou_max"]), j
+    assert int(asg["status"].max()) == 0
+    # the fused loss sees the same lists (regression targets come from the published records)
+    cls = rng.uniform(0.001, 0.6, (bsz, anc.shape[1], c)).astype(np.float32)
+    reg = rng.normal(0, 1, (bsz, anc.shape[1], 4)).astype(np.float32)
+    ref = O.focal_loss_fwd_bwd(cls, reg, anc, ann)
+    out = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
+    assert np.array_equal(out["num_pos"].cpu().numpy(), ref["num_pos"])
+    assert np.allclose(out["losses"].cpu().numpy(),
+                       [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
+    grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+
+
 def make_batch(seed, bsz, size, c, m, valid):
     rng = np.random.default_rng(seed)
     anc = O.anchors_for_image(size, size)
