@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
     float* __restrict__ partials, int N, int C, int M, int total_rows, int num_tiles,
     unsigned magic_c, FocalConst fc, float gcls, float greg, float divisor,
-    const float* __restrict__ pos_total) {
+    const float* __restrict__ pos_total, int parts, int part_vecs) {
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
   __shared__ int s_np[kThreads / 64][2];
@@ -523,7 +523,14 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
   const float k0l = -(1.0f - fc.alpha) * kLn2;
   constexpr int UG = 2;   // unroll of the general (row-tracking) path: keeps registers low
 
-  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+  // A workgroup takes one part of one tile: with many classes a tile's classification block is
+  // cut into `parts` runs of part_vecs float4 (a multiple of the block size), so that every
+  // workgroup streams about as much as it does at C = 80 -- short-lived workgroups whose loads
+  // all go out at once, and enough of them to fill the chip evenly.  Part 0 also does the
+  // tile's regression rows.
+  for (int unit = blockIdx.x; unit < num_tiles * parts; unit += gridDim.x) {
+    const int tile = parts == 1 ? unit : unit / parts;
+    const int part = unit - tile * parts;
     const int row0 = tile * kTileRows;
     const int rows = min(kTileRows, total_rows - row0);
     const int j0 = row0 / N;
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     float cl0 = 0.f, cl1 = 0.f, rl0 = 0.f, rl1 = 0.f;
 
     // ---- regression: 4 lanes per anchor, one coordinate each -----------------
-    {
+    if (part == 0) {
       const int r = tid >> 2, k = tid & 3;
       if (r < rows) {
         const int grow = row0 + r;
@@ -589,21 +596,23 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     v4f* __restrict__ d4 = reinterpret_cast<v4f*>(dprob + base);
     const int elems = rows * C;
     const int nvec = elems >> 2;
+    const int v_begin = part * part_vecs;
+    const int v_end = min(nvec, v_begin + part_vecs);
 
     if (!special && !two) {
       // Every row is a negative of one image: pure elementwise stream, no index maths.
       const float k0g = -(1.0f - fc.alpha) * sc0;
-      for (int v0 = tid; v0 < nvec; v0 += kThreads * U) {
+      for (int v0 = v_begin + tid; v0 < v_end; v0 += kThreads * U) {
         v4f val[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
+          if (v < v_end) val[u] = __builtin_nontemporal_load(&p4[v]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) {
+          if (v < v_end) {
             float g0, g1, g2, g3;
             cl0 += focal_zero_in<kLogits>(val[u].x, fc, k0l, k0g, g0);
             cl0 += focal_zero_in<kLogits>(val[u].y, fc, k0l, k0g, g1);
@@ -616,17 +625,17 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
         }
       }
     } else {
-      for (int v0 = tid; v0 < nvec; v0 += kThreads * UG) {
+      for (int v0 = v_begin + tid; v0 < v_end; v0 += kThreads * UG) {
         v4f val[UG];
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) val[u] = __builtin_nontemporal_load(&p4[v]);
+          if (v < v_end) val[u] = __builtin_nontemporal_load(&p4[v]);
         }
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
           const int v = v0 + u * kThreads;
-          if (v < nvec) {
+          if (v < v_end) {
             const unsigned x = (unsigned)v << 2;
             int r = (int)fast_div(x, magic_c);
             int col = (int)x - r * C;
@@ -672,7 +681,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
       }
     }
     // last tile only: up to 3 trailing elements when B*N*C is not a multiple of 4
-    {
+    if (part == parts - 1) {
       const int x = (nvec << 2) + tid;
       if (x < elems) {
         const int r = x / C, col = x - r * C;
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     __syncthreads();
     if (tid == 0) {
       const float4 a = s_red[0], b = s_red[1], c = s_red[2], d = s_red[3];
-      reinterpret_cast<float4*>(partials)[tile] =
+      reinterpret_cast<float4*>(partials)[unit] =
           make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y),
                       (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
     }
@@ -980,8 +989,8 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
 // Final reduction, one workgroup of 16 waves, fixed order, double accumulation.
 // Wave w sums the partials of images w, w+16, ... (lane-strided, then a butterfly)
 // and applies the normalisers of losses.py:94 and :134; wave 0 then forms the batch
-// means of losses.py:139-141.  tile_mode: partials are the tile kernel's [tile][4]
-// records, else the generic kernel's [B][blocks][2].
+// means of losses.py:139-141.  tile_mode > 0: partials are the tile kernel's records,
+// tile_mode float4 per tile; 0: the row / level kernels' [B][blocks][2].
 // ---------------------------------------------------------------------------
 constexpr int kFinalThreads = 1024;
 
@@ -1004,10 +1013,11 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
         // only the image's first tile can also hold rows of the previous image; there this
         // image is the tile's second one
         const bool shared_first = (first % kTileRows) != 0;
+        const int u_shared = (t_lo + 1) * tile_mode;      // records below it belong to tile t_lo
 #pragma unroll 8
-        for (int t = t_lo + lane; t <= t_hi; t += 64) {
-          const float4 q = reinterpret_cast<const float4*>(partials)[t];
-          const bool second = shared_first && t == t_lo;
+        for (int u = t_lo * tile_mode + lane; u < (t_hi + 1) * tile_mode; u += 64) {
+          const float4 q = reinterpret_cast<const float4*>(partials)[u];
+          const bool second = shared_first && u < u_shared;
           c += second ? q.y : q.x;
           r += second ? q.w : q.z;
         }
@@ -1097,9 +1107,19 @@ struct LossWorkspace {
 
 static bool tile_path_ok(long long n, int c) { return n >= kTileRows && c >= 4 && c < 8192; }
 
+// Parts a tile's classification block is cut into.  Up to 20 float4 per thread the tile is cut
+// into runs of about 10 (one or two batches of loads); wider tiles into runs of about 5, one
+// batch, as at C = 80.  Measured on 8 x 120 087 x 601: 878 us unsplit, 840 us with runs of 10,
+// 802 us with runs of 5; runs of 5 at C = 91..100 (two half-empty parts) cost 20 % instead.
+static int tile_parts(int c) {
+  const int per_thread = (kTileRows * c / 4 + kThreads - 1) / kThreads;
+  const int run = per_thread <= 20 ? 10 : 5;
+  return (per_thread + run - 1) / run;
+}
+
 static long long partial_floats(int batch, long long n, int c) {
   const long long tiles = ((long long)batch * n + kTileRows - 1) / kTileRows;
-  const long long a = tiles * 4, b = (long long)batch * kGenericBlocks * 2;
+  const long long a = tiles * 4 * tile_parts(c), b = (long long)batch * kGenericBlocks * 2;
   return a > b ? a : b;
 }
 
@@ -1329,21 +1349,25 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   }
   if (stages & RH_STAGE_STREAM) {
     if (tile) {
-      // float4 slots per thread and tile: pick the unroll that wastes the fewest
-      const int per_thread = (kTileRows * num_classes / 4 + kThreads - 1) / kThreads;
+      // float4 slots per thread and part: pick the unroll that wastes the fewest
+      const int parts = tile_parts(num_classes);
+      const int tile_vecs = kTileRows * num_classes / 4;
+      const int part_vecs = (int)round_up((tile_vecs + parts - 1) / parts, kThreads);
+      const int per_thread = part_vecs / kThreads;
       const bool u5 = (per_thread + 4) / 5 * 5 < (per_thread + 3) / 4 * 4;
+      RH_REQUIRE((long long)num_tiles * parts < (1ll << 31), RH_ESHAPE, "too many workgroups");
       // One tile per workgroup: the hardware dispatcher balances the 17k+ tiles better than a
       // grid-stride loop did (measured 125 us against 142 us at B=16, N=69354, C=80), and
       // non-temporal loads and stores (the data is touched once) were worth another 8 %.
       auto kern = params->from_logits
                       ? (u5 ? focal_stream_kernel<5, true> : focal_stream_kernel<4, true>)
                       : (u5 ? focal_stream_kernel<5, false> : focal_stream_kernel<4, false>);
-      hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kThreads), 0, s, classifications,
+      hipLaunchKernelGGL(kern, dim3(num_tiles * parts), dim3(kThreads), 0, s, classifications,
                          d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
                          div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
-                         divisor, nrm.total);
+                         divisor, nrm.total, parts, part_vecs);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
       auto kern = params->from_logits ? focal_rows_kernel<true> : focal_rows_kernel<false>;
@@ -1356,8 +1380,8 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
   }
   if (stages & RH_STAGE_FINALIZE) {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
-                       w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n, tile ? 1 : 0,
-                       kGenericBlocks, divisor, nrm.total);
+                       w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n,
+                       tile ? tile_parts(num_classes) : 0, kGenericBlocks, divisor, nrm.total);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;

@@ -25,8 +25,9 @@ def main():
     ap.add_argument("--infer", action="store_true")
     ap.add_argument("--logits", action="store_true", help="loss on logits (sigmoid folded in)")
     ap.add_argument("--levels", action="store_true", help="loss on the heads' [B, A*C, H, W] outputs")
+    ap.add_argument("--shape", help="B,size,C,M instead of --cfg")
     a = ap.parse_args()
-    bsz, size, c, m = CFG[a.cfg]
+    bsz, size, c, m = [int(x) for x in a.shape.split(",")] if a.shape else CFG[a.cfg]
     dev = torch.device("cuda:0")
     anchors = rh.Anchors()(torch.zeros(1, 3, size, size, device=dev))
     n = anchors.shape[1]
