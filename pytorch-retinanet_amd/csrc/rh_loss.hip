@@ -506,8 +506,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // Requirements checked on the host: 4 <= C < 8192, N >= 64, all pointers 16-byte
 // aligned, B*N < 2^31.
 // ---------------------------------------------------------------------------
-// (Double-buffering the loads of wide rows, which take several batches of U float4 per thread,
-// was measured at C = 601 and changed nothing: 886 against 887 us.)
+// (Double-buffering the loads of wide tiles inside one workgroup was measured at C = 601 and
+// changed nothing, 886 against 887 us; cutting them into parts, tile_parts() below, did.)
 template <int U, bool kLogits>
 __global__ __launch_bounds__(kThreads) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
