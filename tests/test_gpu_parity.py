@@ -704,6 +704,54 @@ def test_postprocess_agnostic(rh):
     assert len(tup) == 3 and torch.equal(tup[0], res[0]["scores"])
 
 
+def test_operators_in_the_reference_forward_pattern(rh):
+    """The operators one by one, called the way the tail of the reference forward calls them
+    (models/retinanet/model.py:315-340: anchors, loss in training; decode, clip, max over classes,
+    threshold on image 0, nms, gather in evaluation, with stock torch ops in between): the result is
+    the fused postprocess() bit for bit, and the loss is the fused module's."""
+    cls, reg, anc_ref = infer_batch(21, 2, 192, 12)
+    img = torch.zeros(2, 3, 192, 192, device="cuda")
+    classification, regression = dev(cls), dev(reg)
+    anchors_op, decode_op, clip_op = rh.Anchors(), rh.BBoxTransform(), rh.ClipBoxes()
+    anchors = anchors_op(img)
+    assert np.array_equal(anchors.cpu().numpy(), anc_ref)
+    # evaluation branch
+    boxes = clip_op(decode_op(anchors, regression), img)
+    scores = torch.max(classification, dim=2, keepdim=True)[0]
+    over = (scores > 0.05)[0, :, 0]
+    assert int(over.sum()) > 100
+    cand_cls, cand_boxes, cand_scores = classification[:, over, :], boxes[:, over, :], scores[:, over, :]
+    keep = rh.nms(cand_boxes[0, :, :], cand_scores[0, :, :], 0.5)
+    assert keep.dtype == torch.int64
+    top_scores, top_class = cand_cls[0, keep, :].max(dim=1)
+    top_boxes = cand_boxes[0, keep, :]
+    fused = rh.postprocess(classification, regression, anchors, img, output="tuple")
+    assert torch.equal(fused[0], top_scores) and torch.equal(fused[1], top_class)
+    assert torch.equal(fused[2], top_boxes)
+    s, l, bx = O.postprocess_image(cls[0], reg[0], anc_ref, 192, 192, boxes=boxes[0].cpu().numpy())
+    assert np.array_equal(top_scores.cpu().numpy(), s) and np.array_equal(top_class.cpu().numpy(), l)
+    # the legacy call of the removed extension (model.py:335): dets [K,5] and a threshold
+    keep_legacy = rh.nms(torch.cat([cand_boxes, cand_scores], dim=2)[0, :, :], 0.5)
+    assert torch.equal(keep_legacy, keep)
+    # nothing over the threshold: three empty tensors (model.py:327-329)
+    none = rh.postprocess(classification * 0.0, regression, anchors, img, output="tuple")
+    assert [tuple(t.shape) for t in none] == [(0,), (0,), (0, 4)]
+    # training branch: the dict train.py:181-190 consumes
+    ann = -np.ones((2, 4, 5), np.float32)
+    ann[0, :2] = [[20, 30, 90, 120, 3], [100, 40, 180, 100, 7]]
+    ann[1, :1] = [[60, 60, 130, 150, 0]]
+    c_in, r_in = classification.clone().requires_grad_(True), regression.clone().requires_grad_(True)
+    loss_dict = rh.FocalLoss()(c_in, r_in, anchors, dev(ann))
+    assert set(loss_dict) == {"classification_loss", "regression_loss"}
+    loss = sum(loss for loss in loss_dict.values())
+    loss.backward()
+    ref = O.focal_loss_fwd_bwd(cls, reg, anc_ref, ann)
+    assert np.isclose(loss_dict["classification_loss"].item(), ref["classification_loss"][0], rtol=RTOL)
+    assert np.isclose(loss_dict["regression_loss"].item(), ref["regression_loss"][0], rtol=RTOL)
+    grad_close(c_in.grad.cpu().numpy(), ref["d_classifications"])
+    grad_close(r_in.grad.cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+
+
 def test_postprocess_dense_tiles_and_image_borders(rh):
     """Candidate lists with full 64-row tiles, candidates on both sides of the tile that two
     images share, equal scores, and a capacity that is met exactly."""
