@@ -860,3 +860,40 @@ def test_postprocess_overflow_retry_and_odd_classes(rh):
     check_post(rh, cls, reg, anc, 128, max_candidates=64)      # forces the exact second pass
     cls, reg, anc = infer_batch(4, 1, 64, 3, mu=-2.0)          # C < 4: generic kernel
     check_post(rh, cls, reg, anc, 64)
+
+
+def test_hip_graph_replay_of_both_paths(rh):
+    """The entry points enqueue work only (no allocation, no host read, no synchronisation), so a
+    captured hipGraph of the loss and of the post-processing replays on new data with the results
+    of direct calls, bit for bit."""
+    F = rh.functional
+    size, c = 128, 20
+    batches = [make_batch(31 + i, 2, size, c, 5, [5, 2]) for i in range(3)]
+    anc = dev(batches[0][2])
+    s_cls, s_reg, s_ann = (dev(batches[0][k]) for k in (0, 1, 3))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        loss = F.focal_loss_fwd_bwd(s_cls, s_reg, anc, s_ann)
+        post = F.postprocess_raw(s_cls, s_reg, anc, size, size, score_thresh=0.02)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        F.focal_loss_fwd_bwd(s_cls, s_reg, anc, s_ann, out=loss)
+        F.postprocess_raw(s_cls, s_reg, anc, size, size, score_thresh=0.02, out=post)
+    for cls, reg, _, ann in batches[1:]:
+        s_cls.copy_(dev(cls))
+        s_reg.copy_(dev(reg))
+        s_ann.copy_(dev(ann))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = F.focal_loss_fwd_bwd(dev(cls), dev(reg), anc, dev(ann))
+        for k in ("losses", "total", "per_image", "num_pos", "d_classifications", "d_regressions"):
+            assert torch.equal(loss[k], want[k]), k
+        wpost = F.postprocess_raw(dev(cls), dev(reg), anc, size, size, score_thresh=0.02)
+        assert torch.equal(post["counts"], wpost["counts"]) and int(post["counts"][0].min()) > 0
+        for b in range(2):
+            k = int(post["counts"][0, b])
+            for name in ("scores", "labels", "boxes"):
+                assert torch.equal(post[name][b, :k], wpost[name][b, :k]), name
