@@ -119,8 +119,11 @@ int rh_assign(const float* anchors, const float* annotations, int32_t batch, int
  *   annotations     device [B,M,5]
  *   d_classifications device [B,N,C], d_regressions device [B,N,4]:
  *       gradients of grad_cls*classification_loss + grad_reg*regression_loss
- *   losses          device f32 [3]  {classification_loss, regression_loss} (batch means, :139-141)
- *                                   and their float32 sum (the total train.py:185 forms)
+ *   losses          device f32 [5]  {classification_loss, regression_loss} (batch means, :139-141),
+ *                                   then the call's positive anchors and its images as floats
+ *                                   ([0..3] is the vector data-parallel ranks sum), then
+ *                                   classification_loss + regression_loss in float32 (the total
+ *                                   train.py:185 forms)
  *   per_image       device f32 [2,B] or NULL  (per-image losses, :94 and :134)
  *   num_pos         device i32 [B] or NULL
  *   status          device i32 [B] or NULL  (rh_status_bits per image, written by every call)

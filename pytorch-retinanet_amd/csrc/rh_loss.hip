@@ -1000,11 +1000,14 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor,
     const float* __restrict__ pos_total) {
   __shared__ float s_img[2][kFinalThreads / 64];
+  __shared__ int s_pos[kFinalThreads / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double bc = 0.0, br = 0.0;     // wave 0 only: batch sums, images visited in ascending order
+  long long bp = 0;              // positives of the whole call
   for (int j0 = 0; j0 < B; j0 += kFinalThreads / 64) {
     const int j = j0 + wave;
     float cl = 0.f, rl = 0.f;
+    int pos = 0;
     if (j < B) {
       double c = 0.0, r = 0.0;
       if (tile_mode) {
@@ -1032,6 +1035,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
       c = wave_sum(c);
       r = wave_sum(r);
       np = wave_sum(np);
+      pos = np;
       const bool empty = gt_count[j] == 0;
       // batch-wide normaliser: every image is divided by the one total (an image's share of
       // the batch loss); otherwise by its own count, losses.py:94 and :134
@@ -1050,6 +1054,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     if (lane == 0) {
       s_img[0][wave] = cl;
       s_img[1][wave] = rl;
+      s_pos[wave] = pos;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1057,6 +1062,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
       for (int w = 0; w < kFinalThreads / 64; ++w) {
         bc += s_img[0][w];
         br += s_img[1][w];
+        bp += s_pos[w];
       }
     }
   }
@@ -1064,7 +1070,10 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     const float lc = (float)(bc / (double)divisor), lr = (float)(br / (double)divisor);
     losses[0] = lc;
     losses[1] = lr;
-    losses[2] = lc + lr;   // what train.py:185 forms from the two; saves the caller two launches
+    // what data-parallel ranks exchange beside the two losses, ready in the same 16 bytes
+    losses[2] = (float)bp;
+    losses[3] = (float)B;
+    losses[4] = lc + lr;   // what train.py:185 forms from the two; saves the caller two launches
   }
 }
 

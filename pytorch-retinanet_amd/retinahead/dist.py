@@ -31,6 +31,19 @@ def shard_bounds(global_batch, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class _GlobalValue(torch.autograd.Function):
+    """Forward: the value summed over all ranks; backward: the gradient goes to the local share
+    unchanged (each rank back-propagates its own images).  No launch either way."""
+
+    @staticmethod
+    def forward(ctx, local, value):
+        return value.view_as(local)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 def all_reduce_losses(local_losses, group=None):
     """Sums the loss vectors (any length; entries without grad are plain sums) of all ranks.
     The value is the global sum, the gradient is that of the local share (each rank
@@ -39,7 +52,7 @@ def all_reduce_losses(local_losses, group=None):
         return local_losses
     total = local_losses.detach().clone()
     dist_.all_reduce(total, op=dist_.ReduceOp.SUM, group=group)
-    return local_losses + (total - local_losses.detach())
+    return _GlobalValue.apply(local_losses, total)
 
 
 def all_reduce_num_pos(num_pos, group=None):
@@ -69,14 +82,19 @@ class DataParallelFocalLoss(torch.nn.Module):
 
     def forward(self, classifications, regressions, anchors, annotations):
         out = self.loss_fn(classifications, regressions, anchors, annotations)
-        cls_l, reg_l = out["classification_loss"].reshape(1), out["regression_loss"].reshape(1)
+        cls_l, reg_l = out["classification_loss"], out["regression_loss"]
         last = getattr(self.loss_fn, "last", None)
-        if last is not None and "num_pos" in last:
-            counts = torch.stack([last["num_pos"].sum().to(cls_l.dtype),
-                                  cls_l.new_tensor(float(last["num_pos"].numel()))])
+        if not (dist_.is_available() and dist_.is_initialized()) or dist_.get_world_size(self.group) == 1:
+            if last is not None and "exchange" in last:
+                self.last_global = {"num_pos": last["exchange"][2], "images": last["exchange"][3]}
+            return out
+        if last is not None and "exchange" in last:
+            # the finalize kernel left (both losses, positive anchors, images) side by side
+            vec = last["exchange"].clone()
         else:
-            counts = cls_l.new_zeros(2)
-        vec = all_reduce_losses(torch.cat([cls_l, reg_l, counts]), self.group)
+            vec = torch.cat([cls_l.detach().reshape(1), reg_l.detach().reshape(1), cls_l.new_zeros(2)])
+        dist_.all_reduce(vec, op=dist_.ReduceOp.SUM, group=self.group)
         # global counts of the step, device tensors: positive anchors and images over all ranks
-        self.last_global = {"num_pos": vec[2].detach(), "images": vec[3].detach()}
-        return {"classification_loss": vec[0:1], "regression_loss": vec[1:2]}
+        self.last_global = {"num_pos": vec[2], "images": vec[3]}
+        return {"classification_loss": _GlobalValue.apply(cls_l.reshape(1), vec[0:1]),
+                "regression_loss": _GlobalValue.apply(reg_l.reshape(1), vec[1:2])}

@@ -212,7 +212,8 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
                        batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False,
                        normalizer="per_image", num_pos_total=None):
     """Runs the fused loss kernels.  Returns a dict of device tensors:
-    losses [2], total [1] (their sum; adjacent in memory), per_image [2,B], num_pos [B], status [B],
+    losses [2], exchange [4] (the losses, the call's positive anchors and its images: what
+    data-parallel ranks sum), total [1] (the losses' sum), per_image [2,B], num_pos [B], status [B],
     d_classifications, d_regressions.
     ``out`` may carry buffers from an earlier call (used when stages are run one at a time).
     ``normalizer='global'``: one positive count for the whole batch instead of the reference's
@@ -232,14 +233,16 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     m = ann.shape[1]
     lib = _lib.load()
     if out is None:
-        # one small allocation for all scalar-ish outputs: [losses 2 | per_image 2B | num_pos B | status B]
-        small = torch.empty((3 + 4 * bsz,), dtype=torch.float32, device=dev)
+        # one small allocation for all scalar-ish outputs:
+        # [losses 2, positives 1, images 1, total 1 | per_image 2B | num_pos B | status B]
+        small = torch.empty((5 + 4 * bsz,), dtype=torch.float32, device=dev)
         out = dict(
             losses=small[0:2],
-            total=small[2:3],
-            per_image=small[3:3 + 2 * bsz].view(2, bsz),
-            num_pos=small[3 + 2 * bsz:3 + 3 * bsz].view(torch.int32),
-            status=small[3 + 3 * bsz:].view(torch.int32),
+            exchange=small[0:4],
+            total=small[4:5],
+            per_image=small[5:5 + 2 * bsz].view(2, bsz),
+            num_pos=small[5 + 2 * bsz:5 + 3 * bsz].view(torch.int32),
+            status=small[5 + 3 * bsz:].view(torch.int32),
             d_classifications=torch.empty_like(cls),
             d_regressions=torch.empty_like(reg),
         )
@@ -297,7 +300,7 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
     nl = len(cls)
     lib = _lib.load()
     if out is None:
-        small = torch.empty((3 + 4 * bsz,), dtype=torch.float32, device=dev)
+        small = torch.empty((5 + 4 * bsz,), dtype=torch.float32, device=dev)
         d_cls_all = torch.empty((sum(t.numel() for t in cls),), dtype=torch.float32, device=dev)
         d_reg_all = torch.empty((sum(t.numel() for t in reg),), dtype=torch.float32, device=dev)
 
@@ -309,10 +312,11 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
             return res
         out = dict(
             losses=small[0:2],
-            total=small[2:3],
-            per_image=small[3:3 + 2 * bsz].view(2, bsz),
-            num_pos=small[3 + 2 * bsz:3 + 3 * bsz].view(torch.int32),
-            status=small[3 + 3 * bsz:].view(torch.int32),
+            exchange=small[0:4],
+            total=small[4:5],
+            per_image=small[5:5 + 2 * bsz].view(2, bsz),
+            num_pos=small[5 + 2 * bsz:5 + 3 * bsz].view(torch.int32),
+            status=small[5 + 3 * bsz:].view(torch.int32),
             d_cls_all=d_cls_all, d_reg_all=d_reg_all,
             d_cls_levels=views(d_cls_all, cls), d_reg_levels=views(d_reg_all, reg),
         )

@@ -150,7 +150,7 @@ class _DenseHeadLossFn(torch.autograd.Function):
         ctx.in_dtypes = (classifications.dtype, regressions.dtype)
         # keep only the small outputs: a second reference to the gradient buffers would make
         # autograd's AccumulateGrad copy them (hundreds of MB) instead of adopting them
-        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
+        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status", "exchange")}
         ctx.set_materialize_grads(False)
         return _loss_outputs(out)       # fresh storage every call: no copy needed
 
@@ -184,7 +184,7 @@ class _DenseHeadLevelsLossFn(torch.autograd.Function):
         ctx.grads = (out["d_cls_levels"], out["d_reg_levels"])
         ctx.expected = cfg["expected_grad"]
         ctx.in_dtypes = [t.dtype for t in levels]
-        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status")}
+        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status", "exchange")}
         ctx.set_materialize_grads(False)
         return _loss_outputs(out)
 
@@ -248,7 +248,8 @@ class FocalLoss(nn.Module):
 
     @property
     def last(self):
-        """Device tensors of the latest call: per_image [2,B], num_pos [B], status [B]."""
+        """Device tensors of the latest call: per_image [2,B], num_pos [B], status [B], exchange [4]
+        (both losses, positive anchors, images: the vector data-parallel ranks sum)."""
         return self.cfg["last"]
 
     def forward(self, classifications, regressions, anchors, annotations):

@@ -301,7 +301,7 @@ def test_loss_sum_uses_the_stored_total(rh, focal_golden):
             loss = sum(l for l in out.values())
             assert isinstance(loss, torch.Tensor) and loss.shape == (1,)
             assert loss.item() == (c.detach().clone() + r.detach().clone()).item()
-            assert loss.data_ptr() == c.data_ptr() + 8                   # the stored total, no new tensor
+            assert loss.data_ptr() == c.data_ptr() + 16                  # the stored total, no new tensor
             again = sum(out.values())                                    # handed out once: a new tensor
             assert again.data_ptr() != loss.data_ptr() and again.item() == loss.item()
         elif how == "plain_add":
@@ -444,6 +444,9 @@ def test_global_normaliser_vs_oracle(rh, bsz, size, c, m, valid):
     assert np.allclose(out["losses"].cpu().numpy(),
                        [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
     assert out["total"].item() == (out["losses"][0] + out["losses"][1]).item()
+    # the vector data-parallel ranks sum: both losses, the call's positives, its images
+    assert out["exchange"].tolist() == [out["losses"][0].item(), out["losses"][1].item(),
+                                        float(ref["num_pos"].sum()), float(bsz)]
     pi = out["per_image"].cpu().numpy()
     assert np.allclose(pi[0], ref["cls_per_image"], rtol=RTOL, atol=0)
     assert np.allclose(pi[1], ref["reg_per_image"], rtol=RTOL, atol=0)
