@@ -323,11 +323,16 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
     params = _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor,
                            from_logits, normalizer, num_pos_total, dev)
     ptrs = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
-    ints = lambda vs: (C.c_int32 * nl)(*vs)
-    h_arr, w_arr = ints(hs), ints(wsz)
-    need = lib.rh_focal_loss_levels_workspace_bytes(bsz, nl, h_arr, w_arr, a, m)
-    if need == 0:
-        raise RetinaHeadError("focal_loss_levels: " + _lib.last_error())
+    shape_key = ("levels", bsz, tuple(hs), tuple(wsz), a, m)
+    hit = _ws_bytes_cache.get(shape_key)
+    if hit is None:
+        ints = lambda vs: (C.c_int32 * nl)(*vs)
+        h_arr, w_arr = ints(hs), ints(wsz)
+        need = lib.rh_focal_loss_levels_workspace_bytes(bsz, nl, h_arr, w_arr, a, m)
+        if need == 0:
+            raise RetinaHeadError("focal_loss_levels: " + _lib.last_error())
+        hit = _ws_bytes_cache[shape_key] = (h_arr, w_arr, need)
+    h_arr, w_arr, need = hit
     with _on_device(dev) as stream:
         ws = workspace(dev, need, "focal_levels", stream)
         _lib.check(lib.rh_focal_loss_levels_fwd_bwd(
