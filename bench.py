@@ -203,7 +203,9 @@ def main():
             cls.grad = None
             reg.grad = None
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: calls made meanwhile by other threads of the process (the collective
+            # library's watchdog polls events) cannot invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_out = local_step()
             launch = "hipGraph replay of FocalLoss forward + backward"
         except Exception as e:                   # pragma: no cover - depends on the runtime
