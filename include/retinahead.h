@@ -244,6 +244,17 @@ int rh_match_detections(const float* det_boxes, const int64_t* det_labels, const
 int rh_collate_annotations_f32(const float* boxes, const float* labels, const int32_t* offsets,
                                int32_t batch, int32_t m, float* out, rh_stream_t stream);
 
+/* The same with the datasets' annotation filter folded in (csv_dataset.py:129-136,
+ * coco_dataset.py:97-108): a row whose width or height is below min_size is dropped (the
+ * reference uses 1; a NaN extent is kept, as there), rows given as [x, y, w, h] (xywh != 0, the
+ * COCO form, width / height tested as stored) become corners by x + w, y + h; survivors keep their
+ * order, the rest of out[b] is -1.  kept: device i32 [B] or NULL, rows kept per image (out needs
+ * m >= the largest of them; m >= the largest raw count always suffices). */
+int rh_sanitize_collate_annotations_f32(const float* boxes, const float* labels,
+                                        const int32_t* offsets, int32_t batch, int32_t m,
+                                        float min_size, int32_t xywh, float* out, int32_t* kept,
+                                        rh_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Box decode and clip  -  replace BBoxTransform.forward (utils.py:96-120) and
  * ClipBoxes.forward (utils.py:133-142).

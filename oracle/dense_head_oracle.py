@@ -477,14 +477,36 @@ def postprocess_image(classification, regression, anchors, height, width,
 # --------------------------------------------------------------------------
 # Annotation collation  (reference: models/retinanet/model.py:27, 43-55)
 # --------------------------------------------------------------------------
-def collate_annotations(targets):
+def sanitize_annotations(boxes, labels, min_size=1.0, xywh=False):
+    """The annotation filter of the reference's dataset loaders, for float32 rows: drop a row
+    whose width or height is below ``min_size`` (csv_dataset.py:129-136 tests x2 - x1 / y2 - y1,
+    coco_dataset.py:97-99 the stored w / h; ``nan < 1`` is false, so a NaN extent stays), turn
+    [x, y, w, h] into corners by x + w, y + h (coco_dataset.py:106-108), keep the order.
+    Unpinned: the loaders import pycocotools / skimage / torchvision, absent here, so they cannot
+    run; the rule is restated from the lines cited."""
+    b = np.asarray(boxes, F32).reshape(-1, 4).copy()
+    l = np.asarray(labels, F32).reshape(-1)
+    if xywh:
+        w, h = b[:, 2].copy(), b[:, 3].copy()
+        b[:, 2] = b[:, 0] + w
+        b[:, 3] = b[:, 1] + h
+    else:
+        w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    keep = ~((w < F32(min_size)) | (h < F32(min_size)))
+    return b[keep], l[keep]
+
+
+def collate_annotations(targets, min_size=None, xywh=False):
     """[B, M, 5] float32: image b's rows (x1, y1, x2, y2, label), padded with -1 to the largest
-    count (one row when every image is empty, model.py:55).  ``targets``: list of
-    (boxes [m,4], labels [m]) pairs.  The reference function itself cannot run (it returns an
-    undefined name, model.py:66), so this restatement is unpinned; it is a plain copy loop."""
+    count of the input lists (one row when every image is empty, model.py:55).  ``targets``:
+    list of (boxes [m,4], labels [m]) pairs.  The reference function itself cannot run (it returns
+    an undefined name, model.py:66), so this restatement is unpinned; it is a plain copy loop.
+    ``min_size`` / ``xywh``: :func:`sanitize_annotations` applied to every image first."""
     m = max([len(b) for b, _ in targets] + [1])
     out = -np.ones((len(targets), m, 5), F32)
     for i, (b, l) in enumerate(targets):
+        if min_size is not None or xywh:
+            b, l = sanitize_annotations(b, l, -np.inf if min_size is None else min_size, xywh)
         k = len(b)
         if k:
             out[i, :k, :4] = np.asarray(b, F32).reshape(k, 4)

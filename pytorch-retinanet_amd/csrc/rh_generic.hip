@@ -81,6 +81,48 @@ __global__ __launch_bounds__(kThreads) void collate_annotations_kernel(
   for (int k = 0; k < 5; ++k) out[i * 5 + k] = r[k];
 }
 
+// Collation with the datasets' annotation filter folded in: rows narrower or lower than
+// min_size are dropped (csv_dataset.py:129-136 on x2 - x1 / y2 - y1, coco_dataset.py:97-99 on the
+// stored width / height; a NaN extent is kept, as `nan < 1` is false there), [x, y, w, h] rows
+// become corners by x + w, y + h (coco_dataset.py:106-108), the survivors keep their order.
+// One wave per image, 64 rows at a time, positions from a ballot prefix count.
+__global__ __launch_bounds__(64) void sanitize_collate_kernel(
+    const float* __restrict__ boxes, const float* __restrict__ labels,
+    const int* __restrict__ offsets, float* __restrict__ out, int* __restrict__ kept, int M,
+    float min_size, int xywh) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int lo = offsets[b], count = offsets[b + 1] - lo;
+  float* ob = out + (size_t)b * M * 5;
+  int cnt = 0;
+  for (int m0 = 0; m0 < count; m0 += 64) {
+    const int m = m0 + lane;
+    const bool have = m < count;
+    const size_t t = (size_t)lo + (have ? m : count - 1);
+    float x1 = boxes[t * 4 + 0], y1 = boxes[t * 4 + 1], x2 = boxes[t * 4 + 2], y2 = boxes[t * 4 + 3];
+    const float lab = labels[t];
+    float w, h;
+    if (xywh) {
+      w = x2;
+      h = y2;
+      x2 = x1 + w;
+      y2 = y1 + h;
+    } else {
+      w = x2 - x1;
+      h = y2 - y1;
+    }
+    const bool keep = have && !(w < min_size || h < min_size);
+    const unsigned long long km = __ballot(keep);
+    const int at = cnt + __popcll(km & ((1ull << lane) - 1ull));
+    if (keep && at < M) {
+      float* o = ob + (size_t)at * 5;
+      o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = lab;
+    }
+    cnt += __popcll(km);
+  }
+  for (int i = min(cnt, M) * 5 + lane; i < M * 5; i += 64) ob[i] = -1.0f;
+  if (kept && lane == 0) kept[b] = cnt;
+}
+
 // Greedy matching of one image's detections to its annotations for detection evaluation
 // (csv_eval.py:188-208).  Detections come in descending score order; a detection is a true
 // positive when its best-overlapping annotation of the same class (first on ties) reaches the
@@ -186,6 +228,19 @@ int rh_collate_annotations_f32(const float* boxes, const float* labels, const in
   hipLaunchKernelGGL(collate_annotations_kernel, dim3((unsigned)((rows + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, (hipStream_t)stream, boxes, labels, offsets, out, batch, m);
   RH_CHECK_LAUNCH("collate_annotations_kernel");
+  return RH_OK;
+}
+
+int rh_sanitize_collate_annotations_f32(const float* boxes, const float* labels,
+                                        const int32_t* offsets, int32_t batch, int32_t m,
+                                        float min_size, int32_t xywh, float* out, int32_t* kept,
+                                        rh_stream_t stream) {
+  RH_REQUIRE(batch >= 1 && m >= 1, RH_ESHAPE, "bad shape batch=%d m=%d", batch, m);
+  RH_REQUIRE(offsets && out, RH_EINVAL, "null pointer");
+  RH_REQUIRE(min_size == min_size, RH_EINVAL, "min_size is NaN");
+  hipLaunchKernelGGL(sanitize_collate_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, boxes,
+                     labels, offsets, out, kept, m, min_size, xywh ? 1 : 0);
+  RH_CHECK_LAUNCH("sanitize_collate_kernel");
   return RH_OK;
 }
 

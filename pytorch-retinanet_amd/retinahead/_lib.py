@@ -93,6 +93,7 @@ SIGNATURES = {
     "rh_clip_boxes_f32": (C.c_int, [_P, _I64, _F, _F, _P]),
     "rh_sigmoid_f32": (C.c_int, [_P, _P, _I64, _P]),
     "rh_collate_annotations_f32": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
+    "rh_sanitize_collate_annotations_f32": (C.c_int, [_P, _P, _P, _I32, _I32, C.c_float, _I32, _P, _P, _P]),
     "rh_match_detections": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, C.c_double, _P, _P]),
     "rh_nms_workspace_bytes": (_SZ, [_I64]),
     "rh_nms": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),

@@ -408,12 +408,19 @@ def sigmoid(logits):
     return out
 
 
-def collate_annotations(targets, min_rows=1):
+def collate_annotations(targets, min_rows=1, min_size=None, box_format="xyxy", return_counts=False):
     """Pads per-image targets to the ``[B, M, 5]`` annotation tensor the loss reads (rows
     ``x1, y1, x2, y2, label``, padding rows all -1), on the device; replaces the annotation half
     of ``collater`` (models/retinanet/model.py:27,43-55).  ``targets`` is a list of dicts with
     device tensors ``'boxes'`` [m,4] and ``'labels'`` [m] or [m,1]; M is the largest m (at least
-    ``min_rows``: the reference pads an all-empty batch to one row).  No host read of device data."""
+    ``min_rows``: the reference pads an all-empty batch to one row).  No host read of device data.
+
+    ``min_size`` / ``box_format='xywh'`` fold in what the reference's datasets do while loading
+    (csv_dataset.py:129-136, coco_dataset.py:97-108): annotations narrower or lower than
+    ``min_size`` (the reference: 1) are dropped, ``[x, y, w, h]`` rows become corners; survivors keep
+    their order.  ``return_counts`` adds the int32 [B] tensor of rows kept per image."""
+    if box_format not in ("xyxy", "xywh"):
+        raise ValueError("box_format must be 'xyxy' or 'xywh'")
     if not targets:
         raise RetinaHeadError("collate_annotations needs at least one image")
     boxes = [t["boxes"].reshape(-1, 4) for t in targets]
@@ -430,10 +437,24 @@ def collate_annotations(targets, min_rows=1):
     all_labels = _f32c(torch.cat(labels)) if offs[-1] else None
     offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
     out = torch.empty((len(targets), m, 5), dtype=torch.float32, device=dev)
+    plain = min_size is None and box_format == "xyxy"
+    kept = None
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().rh_collate_annotations_f32(
-            _p(all_boxes), _p(all_labels), _p(offsets), len(targets), m, _p(out), _stream(dev)),
-            "rh_collate_annotations_f32")
+        if plain:
+            _lib.check(_lib.load().rh_collate_annotations_f32(
+                _p(all_boxes), _p(all_labels), _p(offsets), len(targets), m, _p(out), _stream(dev)),
+                "rh_collate_annotations_f32")
+        else:
+            kept = torch.empty((len(targets),), dtype=torch.int32, device=dev)
+            floor = float("-inf") if min_size is None else float(min_size)
+            _lib.check(_lib.load().rh_sanitize_collate_annotations_f32(
+                _p(all_boxes), _p(all_labels), _p(offsets), len(targets), m, floor,
+                int(box_format == "xywh"), _p(out), _p(kept), _stream(dev)),
+                "rh_sanitize_collate_annotations_f32")
+    if return_counts:
+        if kept is None:
+            kept = (offsets[1:] - offsets[:-1]).to(torch.int32)
+        return out, kept
     return out
 
 

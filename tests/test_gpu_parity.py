@@ -568,6 +568,39 @@ def test_collate_annotations(rh):
     assert np.array_equal(rh.collate_annotations(tg64).cpu().numpy(), O.collate_annotations(tg))
 
 
+@pytest.mark.parametrize("xywh", [False, True])
+def test_collate_with_the_datasets_annotation_filter(rh, xywh):
+    """min_size / box_format: rows under one pixel in width or height dropped, [x, y, w, h] turned
+    into corners, order kept (csv_dataset.py:129-136, coco_dataset.py:97-108), for lists longer than
+    one 64-row pass, an image that loses every row and an empty image."""
+    rng = np.random.default_rng(8 + xywh)
+    counts = [5, 0, 150, 3, 64]
+    tg = []
+    for k in counts:
+        xy = rng.uniform(0, 500, (k, 2))
+        wh = np.where(rng.random((k, 2)) < 0.3, rng.uniform(0, 1, (k, 2)), rng.uniform(1, 200, (k, 2)))
+        if k == 3:
+            wh[:] = 0.5                                  # nothing survives
+        if k == 150:
+            wh[7] = [1.0, 1.0]                           # exactly one pixel stays
+            wh[8] = [np.nan, 5.0]                        # nan < 1 is false: stays
+        b = np.concatenate([xy, wh if xywh else xy + wh], 1).astype(np.float32)
+        tg.append((b, rng.integers(0, 9, k).astype(np.float32)))
+    want = O.collate_annotations(tg, min_size=1.0, xywh=xywh)
+    got, kept = rh.collate_annotations([{"boxes": dev(b), "labels": dev(l)} for b, l in tg],
+                                       min_size=1.0, box_format="xywh" if xywh else "xyxy",
+                                       return_counts=True)
+    assert got.shape == want.shape
+    assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+    want_kept = [int((want[i, :, 4] != -1).sum()) for i in range(len(tg))]
+    assert kept.tolist() == want_kept and want_kept[1] == 0 and want_kept[3] == 0
+    assert 0 < want_kept[2] < 150
+    if xywh:            # conversion alone, nothing dropped
+        got = rh.collate_annotations([{"boxes": dev(b), "labels": dev(l)} for b, l in tg],
+                                     box_format="xywh")
+        assert np.array_equal(got.cpu().numpy(), O.collate_annotations(tg, xywh=True), equal_nan=True)
+
+
 def test_detection_matching_and_ap_golden(rh):
     """Device matching + host AP against csv_eval.evaluate's results (tests/golden/evaluate.npz)
     and, flag by flag, against the oracle."""

@@ -166,3 +166,17 @@ def test_global_normaliser_is_a_reweighting_of_the_reference_mode(focal_golden):
     twice = O.focal_loss_fwd_bwd(cls, reg, anc, ann, normalizer="global", num_pos_total=2 * int(total))
     assert np.isclose(twice["classification_loss"][0] * 2, glo["classification_loss"][0], rtol=1e-6)
     assert np.allclose(twice["d_regressions"] * 2, glo["d_regressions"], rtol=1e-6, atol=1e-30)
+
+
+def test_annotation_filter_rule():
+    """The datasets' filter restated (unpinned: the loaders cannot be imported here): known answers
+    for the lines cited in the oracle."""
+    boxes = np.array([[10, 10, 10.5, 50], [10, 10, 11, 11], [0, 0, 100, 0.99], [5, 5, 60, 70]], np.float32)
+    labels = np.array([1, 2, 3, 4], np.float32)
+    b, l = O.sanitize_annotations(boxes, labels)                     # csv_dataset.py:135
+    assert l.tolist() == [2.0, 4.0] and np.array_equal(b, boxes[[1, 3]])
+    xywh = np.array([[10, 20, 0.5, 30], [10, 20, 1, 1], [3, 4, 50, 60]], np.float32)
+    b, l = O.sanitize_annotations(xywh, labels[:3], xywh=True)       # coco_dataset.py:98, 107-108
+    assert l.tolist() == [2.0, 3.0] and b.tolist() == [[10, 20, 11, 21], [3, 4, 53, 64]]
+    out = O.collate_annotations([(boxes, labels), (xywh[:0], labels[:0])], min_size=1.0)
+    assert out.shape == (2, 4, 5) and (out[0, 2:] == -1).all() and (out[1] == -1).all()
