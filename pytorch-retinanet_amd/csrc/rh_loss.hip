@@ -148,7 +148,8 @@ __global__ __launch_bounds__(kThreads) void assign_kernel(
 
   // Grid (image, block), blocks taken from the last one down: the blocks of the coarse pyramid
   // levels, whose large anchors meet most GT boxes, are the long ones and start first, for
-  // every image at once.
+  // every image at once.  (A one-dimensional grid that also puts the B workgroups reading the
+  // same 512 anchors on one XCD, to share its L2, was measured: 12.0 against 11.5 us.)
   const int j = blockIdx.x;
   const int bx = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
