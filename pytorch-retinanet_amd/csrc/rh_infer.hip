@@ -955,6 +955,8 @@ __global__ __launch_bounds__(kThreads) void nms_mask_general_kernel(const float4
 // instructions: the compiler would wrap each in NaN-quieting moves, more than doubling the
 // count.  Each test shifts its result into the lane's word through the carry
 // (word = 2 * word + test), walking the 32 boxes of a half-word from the highest down.
+// (Pairing two boxes per round so that the subtractions, products and sums become packed
+// float32 instructions cut the instruction count by 13 % and was slower: 21.6 against 19.4 us.)
 // ---------------------------------------------------------------------------
 // word = 2 * word + (a > b)
 __device__ __forceinline__ void shift_in_gt(unsigned& word, const float a, const float b) {
