@@ -156,8 +156,10 @@ __device__ __forceinline__ void emit_tile(const int tile, const int rows, const 
 // whose sigmoid equals the threshold) filters the stream; only elements that pass it are
 // turned into probabilities, and everything after works on those, so arg-max ties and the
 // threshold test are decided on float32 probabilities exactly as in probability mode.
+// At most four waves per SIMD: with the eight its register count allows, the kernel is slower
+// (54.3 against 50.9 us) -- more tiles in flight than the memory system turns over in order.
 template <int U, bool kLogits>
-__global__ __launch_bounds__(kThreads) void score_scan_tile_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 4))) void score_scan_tile_kernel(
     const float* __restrict__ prob, TileCands tc, int C, int total_rows, unsigned magic_c,
     float thresh, float pre) {
   __shared__ u64 s_best[kTileRows];

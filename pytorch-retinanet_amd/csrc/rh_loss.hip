@@ -511,8 +511,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // ---------------------------------------------------------------------------
 // (Double-buffering the loads of wide tiles inside one workgroup was measured at C = 601 and
 // changed nothing, 886 against 887 us; cutting them into parts, tile_parts() below, did.)
+// Five waves per SIMD (at most 96 vector registers; the compiler's own choice was 99, i.e. four
+// waves): measured 120.0 against 121.5 us.  Six waves need spills and take 156 us.
 template <int U, bool kLogits>
-__global__ __launch_bounds__(kThreads) void focal_stream_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
