@@ -511,6 +511,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // ---------------------------------------------------------------------------
 // (Double-buffering the loads of wide tiles inside one workgroup was measured at C = 601 and
 // changed nothing, 886 against 887 us; cutting them into parts, tile_parts() below, did.)
+// (Issuing the first batch of data loads ahead of the code and count loads, which helped the
+// head-layout kernel, gains under 1 % here and costs a spill: not done.)
 // Five waves per SIMD (at most 96 vector registers; the compiler's own choice was 99, i.e. four
 // waves): measured 120.0 against 121.5 us.  Six waves need spills and take 156 us.
 template <int U, bool kLogits>
