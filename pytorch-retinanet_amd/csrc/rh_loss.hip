@@ -137,7 +137,8 @@ __device__ long long rh_dbg[8 * 65536];
 #else
 #define RH_MARK(slot)
 #endif
-__global__ __launch_bounds__(kThreads) void assign_kernel(
+// (at most six waves per SIMD: 11.4 against 11.7 us with eight)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))) void assign_kernel(
     const float4* __restrict__ anchors, const float* __restrict__ ann, GtRec* __restrict__ gt,
     int* __restrict__ gt_count, int* __restrict__ status, int* __restrict__ code,
     unsigned char* __restrict__ state, int* __restrict__ argmax, int* __restrict__ label,
