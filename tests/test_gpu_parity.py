@@ -524,6 +524,34 @@ def test_global_normaliser_module_and_head_layout(rh):
     assert torch.allclose(per["d_regressions"], glo["d_regressions"], rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("size,c", [(64, 8200), (8, 6)])
+def test_shapes_outside_the_tile_kernels(rh, size, c):
+    """More classes than the tile kernels index (C >= 8192) and fewer anchors than one tile
+    (N = 45 for an 8 x 8 image): the row kernels take over, same results."""
+    rng = np.random.default_rng(size + c)
+    anc = O.anchors_for_image(size, size)
+    n = anc.shape[1]
+    assert (n < 64) == (size == 8)
+    bsz = 2
+    cls = rng.uniform(0.0005, 0.3, (bsz, n, c)).astype(np.float32)
+    reg = rng.normal(0, 1, (bsz, n, 4)).astype(np.float32)
+    ann = -np.ones((bsz, 2, 5), np.float32)
+    ann[0, 0] = [*anc[0, 3], c - 1]             # ground truth on top of an anchor: positives for sure
+    ann[1, 1] = [*anc[0, n // 2], 0]
+    ref = O.focal_loss_fwd_bwd(cls, reg, anc, ann)
+    assert ref["num_pos"].sum() > 0
+    out = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
+    assert np.array_equal(out["num_pos"].cpu().numpy(), ref["num_pos"])
+    assert np.allclose(out["losses"].cpu().numpy(),
+                       [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
+    grad_close(out["d_classifications"].cpu().numpy(), ref["d_classifications"])
+    grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
+    # post-processing on the same shapes
+    hot = rng.random((bsz, n)) < 0.3
+    cls[hot, rng.integers(0, c, int(hot.sum()))] = rng.uniform(0.06, 0.99, int(hot.sum())).astype(np.float32)
+    check_post(rh, cls, (0.3 * reg).astype(np.float32), anc, size)
+
+
 def test_label_out_of_range_flag(rh):
     cls, reg, anc, ann = make_batch(9, 1, 64, 4, 3, [3])
     ann[0, 1, 4] = 4.0                                   # == C: IndexError in the reference
