@@ -552,6 +552,31 @@ def test_shapes_outside_the_tile_kernels(rh, size, c):
     check_post(rh, cls, (0.3 * reg).astype(np.float32), anc, size)
 
 
+def test_other_dtypes_and_layouts_go_through_float32(rh):
+    """Half / double / non-contiguous inputs are cast to contiguous float32 by the Python layer;
+    gradients come back in the inputs' dtypes and layouts."""
+    cls, reg, anc, ann = make_batch(41, 2, 96, 6, 4, [4, 2])
+    ref = O.focal_loss_fwd_bwd(cls.astype(np.float16).astype(np.float32), reg, anc, ann)
+    c16 = dev(cls).half().requires_grad_(True)
+    r64 = dev(reg).double().requires_grad_(True)
+    out = rh.FocalLoss()(c16, r64, dev(anc), dev(ann).double())
+    sum(out.values()).backward()
+    assert c16.grad.dtype == torch.float16 and r64.grad.dtype == torch.float64
+    assert np.isclose(out["classification_loss"].item(), ref["classification_loss"][0], rtol=RTOL)
+    assert np.allclose(r64.grad.cpu().numpy(), ref["d_regressions"], rtol=1e-5,
+                       atol=REG_ATOL_REL * np.abs(ref["d_regressions"]).max())
+    assert np.allclose(c16.grad.float().cpu().numpy(), ref["d_classifications"], rtol=2e-3, atol=1e-7)
+    # a transposed (non-contiguous) view of the same data
+    base = dev(np.ascontiguousarray(cls.transpose(0, 2, 1))).requires_grad_(True)     # [B, C, N]
+    view = base.transpose(1, 2)                                                       # [B, N, C], strided
+    assert not view.is_contiguous()
+    out2 = rh.FocalLoss()(view, dev(reg), dev(anc), dev(ann))
+    sum(out2.values()).backward()
+    ref32 = O.focal_loss_fwd_bwd(cls, reg, anc, ann)
+    assert base.grad.shape == base.shape
+    grad_close(base.grad.transpose(1, 2).cpu().numpy(), ref32["d_classifications"])
+
+
 def test_label_out_of_range_flag(rh):
     cls, reg, anc, ann = make_batch(9, 1, 64, 4, 3, [3])
     ann[0, 1, 4] = 4.0                                   # == C: IndexError in the reference
