@@ -406,6 +406,7 @@ def main():
                        "kept_per_image": float(counts[0].mean()), "mode": "agnostic, thr 0.05, IoU 0.5",
                        "per_class_images_per_s": BATCH / (per_class_ms * 1e-3)},
     }
+    line["cpu_baseline"] = None
     if not args.no_cpu_baseline and world == 1:      # the host-side baseline is timed at N=1 only
         threads = min(16, os.cpu_count() or 1)
         sample, reps = BATCH, 20
