@@ -75,7 +75,18 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 #endif
 constexpr int kAssignPer = RH_ASSIGN_PER;   // anchors per thread
 constexpr int kAssignBlock = kThreads * kAssignPer;   // anchors per block
-static inline int assign_blocks(long long n) { return (int)((n + kAssignBlock - 1) / kAssignBlock); }
+// Long annotation lists (more than kSplitRows rows per image) take the split form of the kernel:
+// the four waves of a block share one wave's worth of anchors and each scans every fourth
+// 64-row chunk of the list, so the serial walk over the boxes that survive the cull -- on the
+// coarse pyramid levels nearly all of them -- is a quarter as long; the waves' maxima are merged
+// through LDS (larger IoU first, then lower GT index: the first arg-max).
+constexpr int kSplitRows = 128;
+constexpr int kSplitAnchors = 64 * kAssignPer;
+static inline bool assign_split(int m) { return m > kSplitRows; }
+static inline int assign_blocks(long long n, int m) {
+  const int per = assign_split(m) ? kSplitAnchors : kAssignBlock;
+  return (int)((n + per - 1) / per);
+}
 
 // Where the packed codes go.  num_levels == 0: code[j*N + n], the order of the flat [B,N,C]
 // tensors.  Otherwise the head-layout kernel's order: within pyramid level l the codes of
@@ -138,6 +149,7 @@ __device__ long long rh_dbg[8 * 65536];
 #define RH_MARK(slot)
 #endif
 // (at most six waves per SIMD: 11.4 against 11.7 us with eight)
+template <bool kSplit>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))) void assign_kernel(
     const float4* __restrict__ anchors, const float* __restrict__ ann, GtRec* __restrict__ gt,
     int* __restrict__ gt_count, int* __restrict__ status, int* __restrict__ code,
@@ -145,6 +157,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
     float* __restrict__ iou_max, int* __restrict__ blk_pos, int N, int M, int C,
     float neg_thresh, float pos_thresh, CodeLayout lay) {
   __shared__ int s_cnt[kThreads / 64];
+  constexpr int kShare = kSplit ? kSplitAnchors : 1;
+  __shared__ float s_best[kThreads / 64][kShare];
+  __shared__ int s_bidx[kThreads / 64][kShare];
+  __shared__ int s_blab[kThreads / 64][kShare];
   RH_MARK(0);
 
   // Grid (image, block), blocks taken from the last one down: the blocks of the coarse pyramid
@@ -154,7 +170,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
   const int j = blockIdx.x;
   const int bx = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int base = bx * kAssignBlock + threadIdx.x;
+  // anchors of thread t: base + k * stride.  Split form: every wave holds the same anchors.
+  constexpr int kStride = kSplit ? 64 : kThreads;
+  const int base = kSplit ? bx * kSplitAnchors + lane : bx * kAssignBlock + (int)threadIdx.x;
   const float* aj = ann + (size_t)j * M * 5;
   const bool publisher = bx == 0 && wave == 0;
 
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
   for (int k = 0; k < kAssignPer; ++k) {
     // lanes past the last anchor repeat it: their results are not stored, and the wave's
     // bounding box stays what the real anchors make it
-    a[k] = anchors[min(base + k * kThreads, N - 1)];
+    a[k] = anchors[min(base + k * kStride, N - 1)];
   }
   AnnRow next = M > 0 ? load_row(aj, lane, M) : AnnRow{0.f, 0.f, 0.f, 0.f, -1.0f};
   float lo_x = a[0].x, lo_y = a[0].y, hi_x = a[0].z, hi_y = a[0].w;
@@ -214,6 +232,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
       gt[(size_t)j * M + cnt + before] = g;
     }
     if (cnt == 0) lab0 = __builtin_amdgcn_readlane(li, __builtin_ctzll(vm));
+    if (kSplit && ((m0 >> 6) & (kThreads / 64 - 1)) != wave) {   // another wave's chunk
+      cnt += __popcll(vm);
+      continue;
+    }
     // rows whose box reaches into the wave's bounding box; a NaN coordinate is never culled
     const bool apart = (r.x2 <= ux1) | (r.x1 >= ux2) | (r.y2 <= uy1) | (r.y1 >= uy2);
     unsigned long long hm = __ballot(valid & !apart);
@@ -262,10 +284,36 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
   }
   RH_MARK(2);
 
+  if (kSplit) {
+    // merge the waves' results: larger IoU wins, equal IoU goes to the lower GT index (a wave
+    // that found nothing holds IoU 0 at index 0, which only a positive IoU displaces)
+#pragma unroll
+    for (int k = 0; k < kAssignPer; ++k) {
+      s_best[wave][lane + k * 64] = best[k];
+      s_bidx[wave][lane + k * 64] = best_idx[k];
+      s_blab[wave][lane + k * 64] = best_lab[k];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int k = 0; k < kAssignPer; ++k) {
+#pragma unroll
+      for (int w = 1; w < kThreads / 64; ++w) {
+        const float v = s_best[w][lane + k * 64];
+        const int vi = s_bidx[w][lane + k * 64];
+        if (v > best[k] || (v == best[k] && vi < best_idx[k])) {
+          best[k] = v;
+          best_idx[k] = vi;
+          best_lab[k] = s_blab[w][lane + k * 64];
+        }
+      }
+    }
+  }
+
   int npos = 0;
 #pragma unroll
   for (int k = 0; k < kAssignPer; ++k) {
-    const int n = base + k * kThreads;
+    const int n = base + k * kStride;
     int st, cd, lb = -1;
     if (cnt == 0) {
       st = RH_IGNORE;      // losses.py:51-55: the image contributes nothing
@@ -304,13 +352,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
     }
   }
   npos = wave_sum(npos);
-  if (lane == 0) s_cnt[wave] = npos;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
+  if (kSplit) {             // only wave 0 is left, and it holds the block's anchors
+    if (lane == 0) blk_pos[(size_t)j * gridDim.y + bx] = npos;
+  } else {
+    if (lane == 0) s_cnt[wave] = npos;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
 #pragma unroll
-    for (int w = 0; w < kThreads / 64; ++w) t += s_cnt[w];
-    blk_pos[(size_t)j * gridDim.y + bx] = t;
+      for (int w = 0; w < kThreads / 64; ++w) t += s_cnt[w];
+      blk_pos[(size_t)j * gridDim.y + bx] = t;
+    }
   }
   if (publisher) {          // this wave has seen every row of the image
     const bool any_bad = __ballot(bad != 0) != 0ull;
@@ -1149,7 +1201,7 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   LossWorkspace w;
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = assign_blocks(n);
+  w.nblk = assign_blocks(n, m);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
@@ -1173,10 +1225,9 @@ static int launch_assign(const float* anchors, const float* annotations, int bat
                          int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                          unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
                          hipStream_t s, const CodeLayout& lay = CodeLayout{}) {
-  RH_REQUIRE(w.nblk <= 65535, RH_ESHAPE, "n=%lld: at most %d anchors per image", n,
-             65535 * kAssignBlock);
+  RH_REQUIRE(w.nblk <= 65535, RH_ESHAPE, "n=%lld with m=%d: more than 65535 assignment blocks per image", n, m);
   dim3 grid((unsigned)batch, (unsigned)w.nblk);
-  hipLaunchKernelGGL(assign_kernel, grid, dim3(kThreads), 0, s,
+  hipLaunchKernelGGL(assign_split(m) ? assign_kernel<true> : assign_kernel<false>, grid, dim3(kThreads), 0, s,
                      reinterpret_cast<const float4*>(anchors), annotations, w.gt, w.gt_count, status,
                      code, state, argmax, label, iou_max, w.blk_pos, (int)n, m, c, neg_t, pos_t, lay);
   RH_CHECK_LAUNCH("assign_kernel");
@@ -1231,7 +1282,7 @@ static LossWorkspace carve_levels(void* ws, int batch, long long n, int m, long 
   LossWorkspace w;
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = assign_blocks(n);
+  w.nblk = assign_blocks(n, m);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)batch * blocks * 2);
@@ -1296,7 +1347,7 @@ static LossWorkspace carve_assign(void* ws, int batch, long long n, int m) {
   LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = assign_blocks(n);
+  w.nblk = assign_blocks(n, m);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.bytes = cv.off;
   return w;
