@@ -143,6 +143,34 @@ def test_assign_ragged_annotation_rows(rh, m):
     grad_close(out["d_regressions"].cpu().numpy(), ref["d_regressions"], atol_rel=REG_ATOL_REL)
 
 
+def test_assign_ties_across_the_waves_of_the_split_form(rh):
+    """Lists of more than 128 rows are scanned by four waves, every fourth 64-row chunk each, and
+    merged: identical boxes placed in chunks of different waves (and in a later chunk of the same
+    wave) must still resolve to the lowest GT index, the first arg-max of losses.py:61."""
+    rng = np.random.default_rng(77)
+    size, c, m = 192, 5, 300
+    anc = O.anchors_for_image(size, size)
+    ann = -np.ones((2, m, 5), np.float32)
+    for j in range(2):
+        x1, y1 = rng.uniform(0, size - 30, m), rng.uniform(0, size - 30, m)
+        ann[j, :, :4] = np.stack([x1, y1, x1 + rng.uniform(10, 120, m), y1 + rng.uniform(10, 120, m)], 1)
+        ann[j, :, 4] = rng.integers(0, c, m)
+    twin = anc[0, 4000]                       # on top of an anchor: IoU 1 for it, ties for its copies
+    for row in (260, 133, 69, 5):
+        ann[0, row, :4] = twin
+    ann[0, 5, 4], ann[0, 69, 4] = 1, 2        # different labels: the label must be the first row's
+    ann[1, 10:200, 4] = -1                    # image 1: valid rows only in chunks 0, 3 and 4
+    asg = rh.functional.assign(dev(anc), dev(ann), c)
+    for j in range(2):
+        ref = O.assign(anc[0], ann[j])
+        assert int(asg["num_pos"][j]) == ref["num_pos"]
+        assert np.array_equal(asg["argmax"][j].cpu().numpy(), ref["argmax"]), j
+        assert np.array_equal(asg["iou_max"][j].cpu().numpy(), ref["iou_max"]), j
+        assert np.array_equal(asg["state"][j].cpu().numpy(), ref["state"]), j
+        assert np.array_equal(asg["label"][j].cpu().numpy(), ref["label"]), j
+    assert int(asg["argmax"][0, 4000]) == 5 and int(asg["label"][0, 4000]) == 1
+
+
 def make_batch(seed, bsz, size, c, m, valid):
     rng = np.random.default_rng(seed)
     anc = O.anchors_for_image(size, size)
