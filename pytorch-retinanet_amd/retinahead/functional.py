@@ -190,9 +190,70 @@ def assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5):
 # --------------------------------------------------------------------------- fused loss
 _ws_bytes_cache = {}
 
+# Layout of the one small buffer that carries the scalar-ish outputs of a loss call (float32
+# words): [classification loss, regression loss, positives, images, total | per_image 2B |
+# num_pos B (int32) | status B (int32)].
+_SMALL_HEAD = 5
+_SMALL_VIEWS = {
+    "losses": lambda t, b: t[0:2],
+    "exchange": lambda t, b: t[0:4],
+    "total": lambda t, b: t[4:5],
+    "per_image": lambda t, b: t[5:5 + 2 * b].view(2, b),
+    "num_pos": lambda t, b: t[5 + 2 * b:5 + 3 * b].view(torch.int32),
+    "status": lambda t, b: t[5 + 3 * b:5 + 4 * b].view(torch.int32),
+}
+
+
+class LossOutputs(dict):
+    """The outputs of a loss call.  Views of the small buffer (``losses``, ``exchange``, ``total``,
+    ``per_image``, ``num_pos``, ``status``) are made when first asked for: slicing a tensor costs
+    microseconds of host time each, and a training step reads two of the six."""
+
+    def __missing__(self, key):
+        make = _SMALL_VIEWS.get(key)
+        if make is None:
+            raise KeyError(key)
+        small = dict.__getitem__(self, "small")
+        view = make(small, (small.numel() - _SMALL_HEAD) // 4)
+        self[key] = view
+        return view
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in _SMALL_VIEWS
+
+    def small_only(self):
+        """The same small outputs without the gradient buffers."""
+        return LossOutputs(small=dict.__getitem__(self, "small"))
+
+
+def _small_ptrs(out, bsz):
+    small = dict.__getitem__(out, "small") if isinstance(out, LossOutputs) else None
+    if small is None:       # a plain dict from a caller: take its views as they are
+        return (out["losses"].data_ptr(), out["per_image"].data_ptr(), out["num_pos"].data_ptr(),
+                out["status"].data_ptr())
+    base = small.data_ptr()
+    return base, base + 4 * _SMALL_HEAD, base + 4 * (_SMALL_HEAD + 2 * bsz), base + 4 * (_SMALL_HEAD + 3 * bsz)
+
+
+_params_cache = {}
+
 
 def _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor, from_logits,
                   normalizer, num_pos_total, dev):
+    if num_pos_total is None:       # the usual case: one structure per setting, built once
+        key = (alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor, from_logits, normalizer)
+        hit = _params_cache.get(key)
+        if hit is None:
+            if len(_params_cache) > 256:
+                _params_cache.clear()
+            hit = _params_cache[key] = _build_focal_params(*key, None, dev)
+        return hit
+    return _build_focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor,
+                               from_logits, normalizer, num_pos_total, dev)
+
+
+def _build_focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor, from_logits,
+                        normalizer, num_pos_total, dev):
     try:
         norm = _lib.NORMALIZERS[normalizer]
     except KeyError:
@@ -235,14 +296,8 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     if out is None:
         # one small allocation for all scalar-ish outputs:
         # [losses 2, positives 1, images 1, total 1 | per_image 2B | num_pos B | status B]
-        small = torch.empty((5 + 4 * bsz,), dtype=torch.float32, device=dev)
-        out = dict(
-            losses=small[0:2],
-            exchange=small[0:4],
-            total=small[4:5],
-            per_image=small[5:5 + 2 * bsz].view(2, bsz),
-            num_pos=small[5 + 2 * bsz:5 + 3 * bsz].view(torch.int32),
-            status=small[5 + 3 * bsz:].view(torch.int32),
+        out = LossOutputs(
+            small=torch.empty((_SMALL_HEAD + 4 * bsz,), dtype=torch.float32, device=dev),
             d_classifications=torch.empty_like(cls),
             d_regressions=torch.empty_like(reg),
         )
@@ -252,13 +307,13 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     need = _ws_bytes_cache.get(shape_key)
     if need is None:
         need = _ws_bytes_cache[shape_key] = lib.rh_focal_loss_workspace_bytes(bsz, n, c, m)
+    p_losses, p_per_image, p_num_pos, p_status = _small_ptrs(out, bsz)
     with _on_device(dev) as stream:
         ws = workspace(dev, need, "focal", stream)
         _lib.check(lib.rh_focal_loss_fwd_bwd(
             cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), bsz, n, c, m,
             C.byref(params), out["d_classifications"].data_ptr(), out["d_regressions"].data_ptr(),
-            out["losses"].data_ptr(), out["per_image"].data_ptr(), out["num_pos"].data_ptr(),
-            out["status"].data_ptr(), ws.data_ptr(), ws.numel(), int(stages), stream),
+            p_losses, p_per_image, p_num_pos, p_status, ws.data_ptr(), ws.numel(), int(stages), stream),
             "rh_focal_loss_fwd_bwd")
     return out
 
@@ -300,7 +355,6 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
     nl = len(cls)
     lib = _lib.load()
     if out is None:
-        small = torch.empty((5 + 4 * bsz,), dtype=torch.float32, device=dev)
         d_cls_all = torch.empty((sum(t.numel() for t in cls),), dtype=torch.float32, device=dev)
         d_reg_all = torch.empty((sum(t.numel() for t in reg),), dtype=torch.float32, device=dev)
 
@@ -310,13 +364,8 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
                 res.append(flat[at:at + t.numel()].view(t.shape))
                 at += t.numel()
             return res
-        out = dict(
-            losses=small[0:2],
-            exchange=small[0:4],
-            total=small[4:5],
-            per_image=small[5:5 + 2 * bsz].view(2, bsz),
-            num_pos=small[5 + 2 * bsz:5 + 3 * bsz].view(torch.int32),
-            status=small[5 + 3 * bsz:].view(torch.int32),
+        out = LossOutputs(
+            small=torch.empty((_SMALL_HEAD + 4 * bsz,), dtype=torch.float32, device=dev),
             d_cls_all=d_cls_all, d_reg_all=d_reg_all,
             d_cls_levels=views(d_cls_all, cls), d_reg_levels=views(d_reg_all, reg),
         )
@@ -338,8 +387,7 @@ def focal_loss_levels_fwd_bwd(cls_levels, reg_levels, anchors_t, annotations, al
         _lib.check(lib.rh_focal_loss_levels_fwd_bwd(
             ptrs(cls), ptrs(reg), anc.data_ptr(), ann.data_ptr(), bsz, nl, h_arr, w_arr, a, c, m,
             C.byref(params), ptrs(out["d_cls_levels"]), ptrs(out["d_reg_levels"]),
-            out["losses"].data_ptr(), out["per_image"].data_ptr(), out["num_pos"].data_ptr(),
-            out["status"].data_ptr(), ws.data_ptr(), ws.numel(), int(stages), stream),
+            *_small_ptrs(out, bsz), ws.data_ptr(), ws.numel(), int(stages), stream),
             "rh_focal_loss_levels_fwd_bwd")
     return out
 

@@ -98,11 +98,11 @@ def _loss_outputs(out):
     """The three [1] outputs of the autograd node on the call's small buffer.  They share its
     storage without being views of it: autograd refuses in-place operations on views returned by
     a node with several outputs, and train.py:187 (``loss /= iterations``) is one."""
-    losses, total = out["losses"], out["total"]
-    store = losses.untyped_storage()
-    at = losses.storage_offset()
-    return (losses.new_empty(0).set_(store, at, (1,)), losses.new_empty(0).set_(store, at + 1, (1,)),
-            losses.new_empty(0).set_(store, total.storage_offset(), (1,)))
+    small = out["small"]     # [classification loss, regression loss, positives, images, total | ...]
+    store = small.untyped_storage()
+    at = small.storage_offset()
+    return (small.new_empty(0).set_(store, at, (1,)), small.new_empty(0).set_(store, at + 1, (1,)),
+            small.new_empty(0).set_(store, at + 4, (1,)))
 
 
 def _stored_as_is(ctx, g_cls, g_reg, g_total):
@@ -150,7 +150,7 @@ class _DenseHeadLossFn(torch.autograd.Function):
         ctx.in_dtypes = (classifications.dtype, regressions.dtype)
         # keep only the small outputs: a second reference to the gradient buffers would make
         # autograd's AccumulateGrad copy them (hundreds of MB) instead of adopting them
-        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status", "exchange")}
+        cfg["last"] = out.small_only()
         ctx.set_materialize_grads(False)
         return _loss_outputs(out)       # fresh storage every call: no copy needed
 
@@ -184,7 +184,7 @@ class _DenseHeadLevelsLossFn(torch.autograd.Function):
         ctx.grads = (out["d_cls_levels"], out["d_reg_levels"])
         ctx.expected = cfg["expected_grad"]
         ctx.in_dtypes = [t.dtype for t in levels]
-        cfg["last"] = {k: out[k] for k in ("per_image", "num_pos", "status", "exchange")}
+        cfg["last"] = out.small_only()
         ctx.set_materialize_grads(False)
         return _loss_outputs(out)
 
