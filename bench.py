@@ -409,7 +409,7 @@ def main():
     line["cpu_baseline"] = None
     if not args.no_cpu_baseline and world == 1:      # the host-side baseline is timed at N=1 only
         threads = min(16, os.cpu_count() or 1)
-        sample, reps = BATCH, 20
+        sample, reps = BATCH, 60      # about 13 s of CPU work
         v, secs = cpu_baseline(cls_np, reg_np, anc_np, ann_np, sample, threads, reps)
         # parity of the measured path with the port on the benchmark's own batch (1e-5 relative;
         # regression gradients with the float32 floor of the quadratic zone, 4e-6 of the largest)
@@ -424,9 +424,9 @@ def main():
         line["cpu_baseline"] = {"value": v, "unit": "anchors/s", "cores": threads, "kind": "port",
                                 "sample": f"the whole batch ({sample} images, N={n}, C={CLASSES}), "
                                           f"forward+backward, best of {reps} runs of {secs:.2f} s"}
-        pv, psecs = cpu_baseline_post(icls_np, ireg_np, anc_np, SIZE, 4, threads, 3)
+        pv, psecs = cpu_baseline_post(icls_np, ireg_np, anc_np, SIZE, 4, threads, 10)
         line["decode_nms"]["cpu_port_images_per_s"] = pv
-        line["decode_nms"]["cpu_port_sample"] = f"4 images, {threads} threads, best of 3 runs of {psecs:.2f} s"
+        line["decode_nms"]["cpu_port_sample"] = f"4 images, {threads} threads, best of 10 runs of {psecs:.2f} s"
     print(json.dumps(line))
     if world > 1:
         dist.barrier()
