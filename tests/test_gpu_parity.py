@@ -1014,3 +1014,47 @@ def test_hip_graph_replay_of_both_paths(rh):
             k = int(post["counts"][0, b])
             for name in ("scores", "labels", "boxes"):
                 assert torch.equal(post[name][b, :k], wpost[name][b, :k]), name
+
+
+def test_two_host_threads_on_their_own_streams(rh):
+    """nn.DataParallel drives its replicas from several Python threads of one process
+    (train.py:137): the library keeps no mutable global state and the wrappers cache workspaces
+    per stream, so two threads working at once on their own streams get the single-thread results."""
+    import threading
+    F = rh.functional
+    data = [make_batch(51 + i, 2, 128, 20, 5, [5, 3]) for i in range(2)]
+    anc = dev(data[0][2])
+    want = []
+    for cls, reg, _, ann in data:
+        o = F.focal_loss_fwd_bwd(dev(cls), dev(reg), anc, dev(ann))
+        p = F.postprocess_raw(dev(cls), dev(reg), anc, 128, 128, score_thresh=0.02)
+        want.append((o["losses"].clone(), o["d_classifications"].clone(), p["counts"].clone(), p["scores"].clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            cls, reg, _, ann = data[i]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                c, r, a = dev(cls), dev(reg), dev(ann)
+                for _ in range(30):
+                    o = F.focal_loss_fwd_bwd(c, r, anc, a)
+                    p = F.postprocess_raw(c, r, anc, 128, 128, score_thresh=0.02)
+                st.synchronize()
+                kept = p["counts"][0]
+                ok = (torch.equal(o["losses"], want[i][0]) and torch.equal(o["d_classifications"], want[i][1])
+                      and torch.equal(p["counts"], want[i][2])
+                      and all(torch.equal(p["scores"][b, :int(kept[b])], want[i][3][b, :int(kept[b])])
+                              for b in range(2)))
+                if not ok:
+                    errors.append(f"thread {i}: results differ")
+        except Exception as e:                       # surfaced in the main thread below
+            errors.append(f"thread {i}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert not errors, errors
