@@ -47,9 +47,15 @@ enum rh_anchor_state { RH_NEGATIVE = 0, RH_IGNORE = 1, RH_POSITIVE = 2 };
 
 /* Bits of the per-image device status words written by the loss entry points. */
 enum rh_status_bits {
-  RH_STATUS_LABEL_RANGE = 1 /* a valid GT row has a label outside [0, C): the
-                               reference raises IndexError at losses.py:79; here
-                               the anchor is positive with an all-zero target row */
+  RH_STATUS_LABEL_RANGE = 1,  /* a valid GT row has a label outside [0, C): the
+                                 reference raises IndexError at losses.py:79; here
+                                 the anchor is positive with an all-zero target row */
+  RH_STATUS_NONFINITE_BOX = 2 /* a valid GT row has a NaN or infinite coordinate.  In the
+                                 reference the NaN IoU wins torch.max (losses.py:61), so the
+                                 anchor is neither below 0.4 nor at or above 0.5 and is
+                                 ignored; here comparisons skip the non-finite pair and the
+                                 anchor is assigned from its other boxes: results for such
+                                 an image are not the reference's */
 };
 
 int rh_version(void);

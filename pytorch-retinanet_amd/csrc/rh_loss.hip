@@ -217,8 +217,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
     int li = (int)r.lab;
     if (!(r.lab > -1.0f && r.lab < (float)C)) {   // also catches NaN
       li = -1;
-      bad |= valid;
+      bad |= valid ? RH_STATUS_LABEL_RANGE : 0;
     }
+    // a NaN or infinite coordinate: x - x is 0 exactly for finite x only
+    const float span = (r.x1 - r.x1) + (r.y1 - r.y1) + (r.x2 - r.x2) + (r.y2 - r.y2);
+    if (valid && !(span == 0.0f)) bad |= RH_STATUS_NONFINITE_BOX;
     const int before = __popcll(vm & ((1ull << lane) - 1ull));   // valid rows in lower lanes
     if (publisher && valid) {
       GtRec g;
@@ -365,10 +368,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
     }
   }
   if (publisher) {          // this wave has seen every row of the image
-    const bool any_bad = __ballot(bad != 0) != 0ull;
+    const int bits = (__ballot(bad & RH_STATUS_LABEL_RANGE) != 0ull ? RH_STATUS_LABEL_RANGE : 0) |
+                     (__ballot(bad & RH_STATUS_NONFINITE_BOX) != 0ull ? RH_STATUS_NONFINITE_BOX : 0);
     if (lane == 0) {
       gt_count[j] = cnt;
-      if (status) status[j] = any_bad ? RH_STATUS_LABEL_RANGE : 0;
+      if (status) status[j] = bits;
     }
   }
   RH_MARK(3);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libretinahead.so")
 RH_OK = 0
 RH_NEGATIVE, RH_IGNORE, RH_POSITIVE = 0, 1, 2
 RH_STATUS_LABEL_RANGE = 1
+RH_STATUS_NONFINITE_BOX = 2
 STAGE_ASSIGN, STAGE_STREAM, STAGE_FINALIZE, STAGE_ALL = 1, 2, 4, 7
 POST_DECODE, POST_SORT, POST_NMS, POST_ALL = 1, 2, 4, 7
 

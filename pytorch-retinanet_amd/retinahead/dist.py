@@ -31,6 +31,19 @@ def shard_bounds(global_batch, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def all_reduce_sum_(t, group=None):
+    """In-place sum of ``t`` over the ranks of ``group``.  RCCL (backend "nccl") reduces device
+    tensors directly; a host-side backend (gloo: CPU tests, several ranks rehearsing on one
+    card) gets a device tensor staged through the host."""
+    if t.is_cuda and dist_.get_backend(group) != "nccl":
+        host = t.detach().cpu()
+        dist_.all_reduce(host, op=dist_.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist_.all_reduce(t, op=dist_.ReduceOp.SUM, group=group)
+    return t
+
+
 class _GlobalValue(torch.autograd.Function):
     """Forward: the value summed over all ranks; backward: the gradient goes to the local share
     unchanged (each rank back-propagates its own images).  No launch either way."""
@@ -50,8 +63,7 @@ def all_reduce_losses(local_losses, group=None):
     back-propagates its own images)."""
     if not (dist_.is_available() and dist_.is_initialized()) or dist_.get_world_size(group) == 1:
         return local_losses
-    total = local_losses.detach().clone()
-    dist_.all_reduce(total, op=dist_.ReduceOp.SUM, group=group)
+    total = all_reduce_sum_(local_losses.detach().clone(), group)
     return _GlobalValue.apply(local_losses, total)
 
 
@@ -60,7 +72,7 @@ def all_reduce_num_pos(num_pos, group=None):
     2^24)."""
     total = num_pos.sum(dtype=torch.float32).reshape(1)
     if dist_.is_available() and dist_.is_initialized() and dist_.get_world_size(group) > 1:
-        dist_.all_reduce(total, op=dist_.ReduceOp.SUM, group=group)
+        all_reduce_sum_(total, group)
     return total
 
 
@@ -93,7 +105,7 @@ class DataParallelFocalLoss(torch.nn.Module):
             vec = last["exchange"].clone()
         else:
             vec = torch.cat([cls_l.detach().reshape(1), reg_l.detach().reshape(1), cls_l.new_zeros(2)])
-        dist_.all_reduce(vec, op=dist_.ReduceOp.SUM, group=self.group)
+        all_reduce_sum_(vec, self.group)
         # global counts of the step, device tensors: positive anchors and images over all ranks
         self.last_global = {"num_pos": vec[2], "images": vec[3]}
         return {"classification_loss": _GlobalValue.apply(cls_l.reshape(1), vec[0:1]),

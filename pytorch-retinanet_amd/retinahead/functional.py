@@ -6,6 +6,8 @@ only; every computation below is a libretinahead.so kernel.
 from __future__ import annotations
 
 import ctypes as C
+import threading
+from collections import OrderedDict
 from typing import Optional
 
 import torch
@@ -13,7 +15,13 @@ import torch
 from . import _lib
 from ._lib import RetinaHeadError
 
-_workspaces = {}
+# Caches shared by every thread that calls into the package (nn.DataParallel drives its replicas
+# from several Python threads of one process, train.py:137): one lock guards them all.
+_cache_lock = threading.Lock()
+_workspaces = OrderedDict()     # (device, stream, tag) -> uint8 buffer, least recently used first
+_WORKSPACE_SLOTS = 64           # streams come and go: beyond this the oldest entries are dropped
+_capture_workspaces = {}        # the same for calls made under stream capture
+_captured = []                  # every buffer a captured graph may hold the address of: kept for good
 
 
 def _dev_check(*tensors):
@@ -72,14 +80,34 @@ class _on_device:
 
 
 def workspace(dev, nbytes, tag="default", stream=None):
-    """A cached byte buffer per (device, stream, tag); grows, never shrinks."""
+    """A cached byte buffer per (device, stream, tag); grows, never shrinks.
+
+    The C entry points bake the buffer's address into their launches, so a buffer that a stream
+    capture has seen must outlive every replay of that graph.  Calls made during capture
+    therefore use a cache of their own whose buffers are never freed, never handed to an eager
+    call and never replaced in place: a captured call that needs more room gets a new buffer
+    (from the graph's memory pool) and the old one stays alive for the graphs that hold its
+    address.  The captured shapes pin their workspace; graphs captured on one stream share it and
+    must not be replayed concurrently.  Eager entries of streams that are no longer used fall
+    out of the cache in least-recently-used order."""
     if stream is None:
         stream = torch.cuda.current_stream(dev).cuda_stream
     key = (dev.index, stream, tag)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
-        _workspaces[key] = buf
+    capturing = torch.cuda.is_current_stream_capturing()
+    with _cache_lock:
+        cache = _capture_workspaces if capturing else _workspaces
+        buf = cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            # grow in steps of a quarter so that slowly growing shapes do not reallocate every call
+            want = max(int(nbytes), 256) if buf is None else max(int(nbytes), buf.numel() * 5 // 4)
+            buf = torch.empty(want, dtype=torch.uint8, device=dev)
+            cache[key] = buf
+            if capturing:
+                _captured.append(buf)
+        if not capturing:
+            _workspaces.move_to_end(key)
+            while len(_workspaces) > _WORKSPACE_SLOTS:
+                _workspaces.popitem(last=False)
     return buf
 
 
@@ -244,9 +272,11 @@ def _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divis
         key = (alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor, from_logits, normalizer)
         hit = _params_cache.get(key)
         if hit is None:
-            if len(_params_cache) > 256:
-                _params_cache.clear()
-            hit = _params_cache[key] = _build_focal_params(*key, None, dev)
+            hit = _build_focal_params(*key, None, dev)
+            with _cache_lock:
+                if len(_params_cache) > 256:
+                    _params_cache.clear()
+                _params_cache[key] = hit
         return hit
     return _build_focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor,
                                from_logits, normalizer, num_pos_total, dev)

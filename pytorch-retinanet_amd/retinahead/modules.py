@@ -6,6 +6,8 @@ import at model.py:8 with these is the whole integration.
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -65,13 +67,43 @@ class _LossTensor(torch.Tensor):
 _ADD_FUNCS = (torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__, torch.add)
 _BACKWARD = torch.Tensor.backward
 _UNIT = {}      # device index -> float32 [1] tensor of ones that only this module holds
+_UNIT_LOCK = threading.Lock()
 
 
 def _unit_gradient(dev):
     unit = _UNIT.get(dev.index)
     if unit is None:
-        unit = _UNIT[dev.index] = torch.ones(1, dtype=torch.float32, device=dev)
+        with _UNIT_LOCK:        # replicas on several devices start from several threads
+            unit = _UNIT.get(dev.index)
+            if unit is None:
+                unit = _UNIT[dev.index] = torch.ones(1, dtype=torch.float32, device=dev)
     return unit
+
+
+class _CallState:
+    """Small outputs of a module's latest call.  nn.DataParallel (the reference's multi-GPU path,
+    train.py:137) replicates a module by copying its attribute dictionary, so every replica thread
+    shares this object: results are kept per thread (what ``check_labels`` reads right after its
+    own call) and per device (what the caller of the wrapped module finds afterwards)."""
+
+    def __init__(self):
+        self._tls = threading.local()
+        self.by_device = {}
+
+    def __reduce__(self):       # copies and pickles of a module start with an empty record
+        return (_CallState, ())
+
+    def set(self, dev, out):
+        self._tls.last = out
+        self.by_device[dev.index] = out
+
+    @property
+    def mine(self):
+        """This thread's latest call, else the latest call on any device."""
+        out = getattr(self._tls, "last", None)
+        if out is None and self.by_device:
+            out = next(reversed(self.by_device.values()))
+        return out
 
 
 def _is_unit(g):
@@ -150,7 +182,7 @@ class _DenseHeadLossFn(torch.autograd.Function):
         ctx.in_dtypes = (classifications.dtype, regressions.dtype)
         # keep only the small outputs: a second reference to the gradient buffers would make
         # autograd's AccumulateGrad copy them (hundreds of MB) instead of adopting them
-        cfg["last"] = out.small_only()
+        cfg["state"].set(classifications.device, out.small_only())
         ctx.set_materialize_grads(False)
         return _loss_outputs(out)       # fresh storage every call: no copy needed
 
@@ -184,7 +216,7 @@ class _DenseHeadLevelsLossFn(torch.autograd.Function):
         ctx.grads = (out["d_cls_levels"], out["d_reg_levels"])
         ctx.expected = cfg["expected_grad"]
         ctx.in_dtypes = [t.dtype for t in levels]
-        cfg["last"] = out.small_only()
+        cfg["state"].set(anchors.device, out.small_only())
         ctx.set_materialize_grads(False)
         return _loss_outputs(out)
 
@@ -222,7 +254,10 @@ class FocalLoss(nn.Module):
         A data-parallel shard passes the global batch size.
     check_labels: read the device status word after the call (one host
         synchronisation) and raise IndexError for a label outside [0, C), as
-        losses.py:79 does.
+        losses.py:79 does, and ValueError for a valid row with a NaN or infinite
+        coordinate (the reference lets the NaN IoU through: such an anchor is then
+        neither negative nor positive; here the non-finite box is skipped by the
+        comparisons, so the image's assignment can differ -- hence the flag).
     from_logits: ``classifications`` holds the head's logits instead of probabilities:
         the ``nn.Sigmoid`` of models/retinanet/model.py:177,193 is folded into the loss
         kernel (same loss; the gradient is the one autograd gives through
@@ -243,21 +278,33 @@ class FocalLoss(nn.Module):
         self.cfg = dict(alpha=float(alpha), neg_thresh=float(neg_thresh),
                         pos_thresh=float(pos_thresh), expected_grad=float(expected_grad),
                         batch_divisor=int(batch_divisor), from_logits=bool(from_logits),
-                        normalizer=normalizer, reduce_total=None, last=None)
+                        normalizer=normalizer, reduce_total=None, state=_CallState())
         self.check_labels = bool(check_labels)
 
     @property
     def last(self):
         """Device tensors of the latest call: per_image [2,B], num_pos [B], status [B], exchange [4]
-        (both losses, positive anchors, images: the vector data-parallel ranks sum)."""
-        return self.cfg["last"]
+        (both losses, positive anchors, images: the vector data-parallel ranks sum).  Under
+        nn.DataParallel each replica thread sees its own call; ``last_by_device`` has them all."""
+        return self.cfg["state"].mine
+
+    @property
+    def last_by_device(self):
+        """{device index: outputs of the latest call on that device}."""
+        return self.cfg["state"].by_device
+
+    def _check_status(self):
+        bits = int(self.last["status"].max().item())
+        if bits & _lib.RH_STATUS_LABEL_RANGE:
+            raise IndexError("annotation label outside [0, num_classes)")
+        if bits & _lib.RH_STATUS_NONFINITE_BOX:
+            raise ValueError("annotation box with a NaN or infinite coordinate")
 
     def forward(self, classifications, regressions, anchors, annotations):
         cls_loss, reg_loss, total = _DenseHeadLossFn.apply(classifications, regressions, anchors,
                                                            annotations, self.cfg)
         if self.check_labels:
-            if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
-                raise IndexError("annotation label outside [0, num_classes)")
+            self._check_status()
         return _as_loss_dict(cls_loss, reg_loss, total)
 
     def forward_levels(self, cls_levels, reg_levels, anchors, annotations):
@@ -269,8 +316,7 @@ class FocalLoss(nn.Module):
         cls_loss, reg_loss, total = _DenseHeadLevelsLossFn.apply(
             self.cfg, anchors, annotations, len(cls_levels), *cls_levels, *reg_levels)
         if self.check_labels:
-            if int(self.cfg["last"]["status"].max().item()) & _lib.RH_STATUS_LABEL_RANGE:
-                raise IndexError("annotation label outside [0, num_classes)")
+            self._check_status()
         return _as_loss_dict(cls_loss, reg_loss, total)
 
 

@@ -18,6 +18,7 @@ RTOL = 1e-5
 
 # (name, batch, image size, classes, padded GT rows, valid GT rows per image)
 CONFIGS = {
+    "dummy512": (2, 512, 600, 10, 10),         # configs[0]: datasets/dummy_dataset.py:10-32 (labels 1..599)
     "coco608": (16, 608, 80, 20, None),        # the bench.py workload
     "oid800": (8, 800, 601, 8, 8),             # configs[2]: 601-class head, rows of 2404 bytes
     "dense1024": (4, 1024, 80, 256, 256),      # configs[3]: 256 GT boxes per image
@@ -50,7 +51,8 @@ def make_inputs(rh, name, seed=0):
         x1, y1 = np.clip(cx - w / 2, 0, size - 1), np.clip(cy - h / 2, 0, size - 1)
         x2, y2 = np.clip(cx + w / 2, x1 + 1, size), np.clip(cy + h / 2, y1 + 1, size)
         ann[j, :v, :4] = np.stack([x1, y1, x2, y2], 1)
-        ann[j, :v, 4] = rng.integers(0, c, v)
+        # dummy_dataset.py:22 draws its labels from [1, 600)
+        ann[j, :v, 4] = rng.integers(1 if name == "dummy512" else 0, c, v)
     return cls, reg, anchors, torch.from_numpy(ann).to(dev), ann
 
 
@@ -133,12 +135,17 @@ def infer_inputs(rh, bsz, size, c, seed=0, mu=-7.0):
     return cls, reg, anchors
 
 
-@pytest.mark.parametrize("mode,topk", [("agnostic", None), ("per_class", None), ("agnostic", 1000)])
-def test_postprocess_full_size(rh, mode, topk):
-    size, c, bsz = 608, 80, 16
+@pytest.mark.parametrize("mode,topk,shape", [("agnostic", None, None), ("per_class", None, None),
+                                             ("agnostic", 1000, None),
+                                             ("agnostic", None, "dummy512"), ("per_class", None, "dummy512")])
+def test_postprocess_full_size(rh, mode, topk, shape):
+    size, c, bsz, mu = 608, 80, 16, -7.0
     if topk:                      # configs[3]: 1024 px, top-1000 before NMS at 0.05
         size, bsz = 1024, 4
-    cls, reg, anchors = infer_inputs(rh, bsz, size, c)
+    if shape == "dummy512":       # configs[0]: batch 2 at 512 px, 600 classes (a maximum over 600
+        bsz, size, c = CONFIGS[shape][:3]      # elements: lower logits for a similar candidate rate)
+        mu = -8.0
+    cls, reg, anchors = infer_inputs(rh, bsz, size, c, mu=mu)
     res = rh.postprocess(cls, reg, anchors, (size, size), mode=mode, pre_nms_topk=topk)
     assert len(res) == bsz
     boxes_all = rh.ClipBoxes()(rh.BBoxTransform()(anchors, reg), torch.zeros(1, 3, size, size, device="cuda"))
