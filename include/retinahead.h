@@ -14,7 +14,8 @@
  *     text for the calling thread.  Shapes are validated on the host before
  *     any launch, so a bad argument never reaches a kernel.
  *   - All tensors are dense, row-major float32 unless a comment says otherwise.
- *   - Re-entrant: no mutable global state; safe from several host threads.
+ *   - Re-entrant: no mutable global state; safe from several host threads.  (The one
+ *     exception is rh_nms_static, which says so below.)
  *
  * The reference (mesnico/pytorch-retinanet) has no FFI: each entry point names
  * the Python lines it stands in for.
@@ -289,6 +290,23 @@ size_t rh_nms_workspace_bytes(int64_t k);
 int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64_t k,
            float iou_threshold, int64_t* keep, int32_t* keep_count, void* workspace,
            size_t workspace_bytes, rh_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * rh_nms without a workspace argument and without any allocation.  It has no counterpart
+ * in the reference; it exists for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Arguments and
+ * results are those of rh_nms (keep lists are identical), for k <= RH_NMS_STATIC_MAX_BOXES;
+ * a larger k is refused with RH_ESHAPE.
+ * The temporaries live in a fixed device array of 3 MiB inside the library, one copy per
+ * GPU the library runs on, held until the process ends.  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on
+ * different GPUs do not.  The first call on each device looks the array's address up
+ * (hipGetSymbolAddress) and should therefore be made outside stream capture; later calls
+ * only enqueue kernels.
+ * ------------------------------------------------------------------------- */
+#define RH_NMS_STATIC_MAX_BOXES 4096
+int rh_nms_static(const float* boxes, const float* scores, const int32_t* labels, int64_t k,
+                  float iou_threshold, int64_t* keep, int32_t* keep_count, rh_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Inference post-processing for a batch  -  replaces model.py:320-340 (which

@@ -12,6 +12,7 @@
 // Compiled with -ffp-contract=off: box coordinates and IoU values decide integer
 // keep lists that must match a float32 CPU evaluation bit for bit.
 #include "rh_common.h"
+#include <mutex>
 
 namespace rh {
 
@@ -1434,6 +1435,60 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
   out.out_stride = (int)k;
   out.max_keep = (int)k;
   return launch_nms(p, w, iou_threshold, labels != nullptr, out, s);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// rh_nms_static: rh_nms for callers that cannot allocate.  The workspace rh_nms takes from
+// its caller (sort keys, counters, sorted boxes and labels, predecessor mask) lives in a
+// file-scope device array instead.  Each GPU holds its own copy of the array at its own
+// address; in host code the array's name is only a handle, so the address is looked up once
+// per device with hipGetSymbolAddress and that pointer is what the kernels receive.
+// ---------------------------------------------------------------------------
+#define RH_NMS_STATIC_BYTES (3u << 20)
+static __device__ __align__(256) unsigned char scratch[RH_NMS_STATIC_BYTES];
+
+namespace {
+constexpr int kStaticMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kStaticMaxDevices];   // per device: address of `scratch` there, or null
+
+// Address of the current device's copy of `scratch` (looked up on the first call per device).
+int static_scratch(void** out) {
+  int device = -1;
+  RH_CHECK_HIP(hipGetDevice(&device));
+  RH_REQUIRE(device >= 0 && device < kStaticMaxDevices, RH_EINVAL, "device %d out of range", device);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* ptr = nullptr;
+    RH_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    RH_REQUIRE(ptr != nullptr, RH_ELAUNCH, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return RH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rh_nms_static(const float* boxes, const float* scores, const int32_t* labels, int64_t k,
+                  float iou_threshold, int64_t* keep, int32_t* keep_count, rh_stream_t stream) {
+  RH_REQUIRE(k >= 0, RH_ESHAPE, "k=%lld is negative", (long long)k);
+  RH_REQUIRE(k <= RH_NMS_STATIC_MAX_BOXES, RH_ESHAPE,
+             "k=%lld exceeds the %d boxes rh_nms_static has scratch for (use rh_nms with a "
+             "caller-owned workspace)", (long long)k, RH_NMS_STATIC_MAX_BOXES);
+  const size_t need = k > 0 ? rh_nms_workspace_bytes(k) : 0;
+  RH_REQUIRE(need <= RH_NMS_STATIC_BYTES, RH_EWORKSPACE,
+             "internal: %zu bytes needed for k=%lld, %u reserved", need, (long long)k,
+             (unsigned)RH_NMS_STATIC_BYTES);
+  void* ptr = nullptr;
+  if (int e = static_scratch(&ptr)) return e;
+  // Nothing in the scratch has to start at zero: every stage writes what the next one reads,
+  // for this call's k, before it is read.
+  return rh_nms(boxes, scores, labels, k, iou_threshold, keep, keep_count, ptr,
+                RH_NMS_STATIC_BYTES, stream);
 }
 
 // A logit whose sigmoid is certainly below `thresh` in float32 (and -inf / +inf when every /

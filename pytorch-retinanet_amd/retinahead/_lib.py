@@ -19,6 +19,7 @@ STAGE_ASSIGN, STAGE_STREAM, STAGE_FINALIZE, STAGE_ALL = 1, 2, 4, 7
 POST_DECODE, POST_SORT, POST_NMS, POST_ALL = 1, 2, 4, 7
 
 MAX_LEVELS = MAX_RATIOS = MAX_SCALES = 8
+NMS_STATIC_MAX_BOXES = 4096      # RH_NMS_STATIC_MAX_BOXES
 
 
 class AnchorCfg(C.Structure):
@@ -98,6 +99,7 @@ SIGNATURES = {
     "rh_match_detections": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, C.c_double, _P, _P]),
     "rh_nms_workspace_bytes": (_SZ, [_I64]),
     "rh_nms": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _SZ, _P]),
+    "rh_nms_static": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P]),
     "rh_postprocess_workspace_bytes": (_SZ, [_I32, _I64, _I32, C.POINTER(PostParams)]),
     "rh_postprocess": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, C.POINTER(PostParams), _P, _P, _P, _P,
                                  _P, _P, _P, _SZ, _I32, _P]),

@@ -598,6 +598,31 @@ def nms(boxes, scores, iou_threshold, labels: Optional[torch.Tensor] = None):
     return keep[:kept]
 
 
+def nms_static(boxes, scores, iou_threshold, keep, count, labels=None):
+    """``rh_nms_static``: the NMS of :func:`nms` with nothing allocated anywhere -- the caller
+    brings the outputs (``keep`` int64 [K], ``count`` int32 [1]; the first ``count`` entries of
+    ``keep`` are valid) and the library's temporaries sit in a fixed per-GPU array, so the call
+    can be used under stream capture or where device allocation is forbidden.  At most
+    ``_lib.NMS_STATIC_MAX_BOXES`` boxes; calls that overlap on one GPU race.  Inputs must
+    already be float32 / int32, contiguous and 16-byte aligned (nothing is converted or copied)
+    and nothing is read back: returns ``(keep, count)``."""
+    dev = _dev_check(boxes, scores, labels, keep, count)
+    s = scores.reshape(-1)
+    k = boxes.shape[0]
+    for t, dt in ((boxes, torch.float32), (s, torch.float32), (labels, torch.int32),
+                  (keep, torch.int64), (count, torch.int32)):
+        if t is not None and (t.dtype != dt or not t.is_contiguous()):
+            raise RetinaHeadError("nms_static needs contiguous float32 boxes / scores, int32 labels, "
+                                  "int64 keep and int32 count")
+    if boxes.dim() != 2 or boxes.shape[1] != 4 or s.shape[0] != k or keep.numel() < k \
+            or count.numel() < 1 or (labels is not None and labels.numel() != k):
+        raise RetinaHeadError("nms_static expects boxes [K,4], scores [K], keep [>=K], count [1]")
+    with _on_device(dev) as stream:
+        _lib.check(_lib.load().rh_nms_static(_p(boxes), _p(s), _p(labels), k, float(iou_threshold),
+                                             _p(keep), _p(count), stream), "rh_nms_static")
+    return keep, count
+
+
 def postprocess_raw(classifications, regressions, anchors_t, height, width, score_thresh=0.05,
                     iou_thresh=0.5, per_class=False, pre_nms_topk=0, max_det=0, cand_cap=4096,
                     stages=_lib.POST_ALL, out=None, from_logits=False, ws=None):

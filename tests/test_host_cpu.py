@@ -117,6 +117,19 @@ def test_library_exports_every_declared_symbol():
     assert retinahead.load_library().rh_version() == 100
 
 
+def test_static_nms_limit_matches_header_and_scratch_budget():
+    """The entry point that allocates nothing: its stated maximum is the header's macro, and the
+    workspace rh_nms needs at that size fits the library's fixed 3 MiB scratch array."""
+    import re
+    import retinahead
+    from retinahead import _lib
+    text = open(os.path.join(ROOT, "include", "retinahead.h")).read()
+    assert int(re.search(r"#define RH_NMS_STATIC_MAX_BOXES (\d+)", text).group(1)) == _lib.NMS_STATIC_MAX_BOXES
+    lib = retinahead.load_library()
+    need = lib.rh_nms_workspace_bytes(_lib.NMS_STATIC_MAX_BOXES)
+    assert 0 < need <= 3 << 20
+
+
 def test_host_side_queries_without_gpu():
     """Entry points that touch no device: defaults, counts, workspace sizes, argument errors."""
     import retinahead
