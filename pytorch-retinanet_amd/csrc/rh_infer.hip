@@ -19,6 +19,27 @@ namespace rh {
 typedef unsigned long long u64;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Build-time diagnostic (-DRH_TIMELINE): thread 0 of every block stores wall-clock stamps
+// (100 MHz) at the marked places; rh_tl_read() copies them out.  Not part of the shipped library.
+#ifdef RH_TIMELINE
+constexpr int kTlBlocks = 8192, kTlSlots = 8;
+__device__ long long rh_tl[3][kTlBlocks][kTlSlots];
+#define RH_TL(kernel, slot)                                                                     \
+  do {                                                                                          \
+    if (threadIdx.x == 0)                                                                       \
+      rh_tl[kernel][(blockIdx.y * gridDim.x + blockIdx.x) % kTlBlocks][slot] = wall_clock64();  \
+  } while (0)
+#define RH_TL_VALUE(kernel, slot, v)                                                            \
+  do {                                                                                          \
+    if (threadIdx.x == 0) rh_tl[kernel][(blockIdx.y * gridDim.x + blockIdx.x) % kTlBlocks][slot] = (v); \
+  } while (0)
+#define RH_TL_DO(...) __VA_ARGS__
+#else
+#define RH_TL(kernel, slot)
+#define RH_TL_VALUE(kernel, slot, v)
+#define RH_TL_DO(...)
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kTileRows = 64;
 constexpr int kSortThreads = 1024;
@@ -484,16 +505,61 @@ __device__ __forceinline__ int gather_image_keys(const int j, const SortSrc src,
   return *s_count;
 }
 
+// Where the sort stage leaves its results, per image j.
+//   keys [j*key_stride + r], sbox / slabel [j*box_stride + r]: candidate of rank r (descending
+//     score, then ascending index), r < boxes passed on;
+//   nz [(j*box_stride + r)*nzw + g]: bitmap of the non-zero predecessor words of box r
+//     (bit w of word g: word g*64 + w), zeroed here and raised by the pair kernel;
+//   cbox / cinfo [j*list_stride + q]: the same boxes in LIST order q (the order the candidates
+//     had before sorting: ascending anchor index from the score scan, the caller's order for a
+//     plain NMS), with (rank or -1 when the box was cut by the top-k, label, bits of the box's
+//     float32 area, 0).  Neighbours in
+//     that order are neighbours in the image, which is what the pair kernel's culling needs;
+//   csum [(j*clusters + g)*2 ..]: for cluster g = list entries [64g, 64g + 64): the bounding box of
+//     its boxes that passed, then (smallest area, largest area, 0, 0).
+//     All three are null when the sort path does not produce them;
+//   mask [j][w][r]: the predecessor words; the rank sort zeroes the words the NMS can touch.
+struct SortOut {
+  u64* keys;
+  float4* sbox;
+  int* slabel;
+  u64* nz;
+  float4* cbox;
+  int4* cinfo;
+  float4* csum;
+  u64* mask;
+  int key_stride, box_stride, list_stride, nzw, wstride, clusters;
+};
+
+// Bounding box and area range of the wave's boxes (lanes with ok == false take no part); every
+// lane gets the result.  An empty cluster gets an inverted box that nothing intersects.
+struct ClusterSummary {
+  float x1, y1, x2, y2, amin, amax;
+};
+__device__ __forceinline__ ClusterSummary summarize_cluster(const float4 b, const bool ok) {
+  const float inf = __builtin_inff();
+  const float area = (b.z - b.x) * (b.w - b.y);
+  ClusterSummary c;
+  c.x1 = wave_extreme<false>(ok ? b.x : inf);
+  c.y1 = wave_extreme<false>(ok ? b.y : inf);
+  c.x2 = wave_extreme<true>(ok ? b.z : -inf);
+  c.y2 = wave_extreme<true>(ok ? b.w : -inf);
+  c.amin = wave_extreme<false>(ok ? area : inf);
+  c.amax = wave_extreme<true>(ok ? area : -inf);
+  return c;
+}
+
 // Writes sorted candidate i of image j: its key, box and label.
 __device__ __forceinline__ void store_sorted(const u64 key, const int i, const int j,
-                                             const SortSrc src, u64* __restrict__ keys_out,
-                                             float4* __restrict__ sbox, int* __restrict__ slabel) {
-  keys_out[i] = key;
+                                             const SortSrc src, const SortOut so) {
+  so.keys[(size_t)j * so.key_stride + i] = key;
+  const size_t o = (size_t)j * so.box_stride + i;
+  for (int g = 0; g < so.nzw; ++g) so.nz[o * so.nzw + g] = 0ull;
   const unsigned idx = key_index(key);
   if (src.from_tiles) {
     const unsigned n = idx - (unsigned)j * (unsigned)src.N;
-    sbox[i] = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
-                       src.height);
+    so.sbox[o] = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
+                          src.height);
     const unsigned t = src.tiles_per_image > 0
                            ? (unsigned)(j * src.tiles_per_image + src.lv.tile_of((int)n))
                            : idx >> 6;
@@ -501,10 +567,10 @@ __device__ __forceinline__ void store_sorted(const u64 key, const int i, const i
     int lab = 0;
     for (int r = 0; r < c; ++r)
       if (src.tc.key[src.tc.at((int)t, r)] == key) lab = src.tc.lab[src.tc.at((int)t, r)];
-    slabel[i] = lab;
+    so.slabel[o] = lab;
   } else {
-    sbox[i] = src.boxes[idx];
-    slabel[i] = src.labels ? src.labels[idx] : 0;
+    so.sbox[o] = src.boxes[idx];
+    so.slabel[o] = src.labels ? src.labels[idx] : 0;
   }
 }
 
@@ -526,9 +592,10 @@ __device__ __forceinline__ u64 bitonic_wave_steps(u64 key, const int index, cons
 
 // One workgroup per image; the whole key array lives in LDS (bitonic network, descending).
 // counters: [3][B] = candidates found, candidates dropped for lack of room, boxes passed on.
-__global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
-    u64* __restrict__ keys, int* __restrict__ counters, int batch, int cap, int key_stride,
-    int topk, SortSrc src, float4* __restrict__ sbox, int* __restrict__ slabel, int box_stride) {
+__global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(int* __restrict__ counters, int batch,
+                                                                int cap, int topk, SortSrc src,
+                                                                SortOut so) {
+  const int key_stride = so.key_stride;
   // one dynamic LDS array: key_stride keys, then the gather counter (a separate static
   // __shared__ object could shift the dynamic base off its 16-byte alignment)
   extern __shared__ __attribute__((aligned(16))) u64 s_keys[];
@@ -536,7 +603,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  u64* kj = keys + (size_t)j * key_stride;
+  u64* kj = so.keys + (size_t)j * key_stride;
   int found;
   if (src.from_tiles) {
     found = gather_image_keys(j, src, s_keys, cap, s_count);
@@ -576,9 +643,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
     __syncthreads();
   }
   const int ke = topk > 0 ? min(K, topk) : K;
-  for (int i = tid; i < ke; i += kSortThreads)
-    store_sorted(s_keys[i], i, j, src, kj, sbox + (size_t)j * box_stride,
-                 slabel + (size_t)j * box_stride);
+  for (int i = tid; i < ke; i += kSortThreads) store_sorted(s_keys[i], i, j, src, so);
   if (tid == 0) {
     counters[j] = found;
     counters[batch + j] = max(found - cap, 0);
@@ -600,7 +665,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(
 // score > mine for entries after them; only the block's own 64 entries need the full key.
 // The owner then decodes the box and writes (key, box, label) at its rank.
 // ---------------------------------------------------------------------------
-constexpr int kRankMax = 4096;
+constexpr int kRankMax = 8192;   // 12 bytes of LDS per key: 96 KiB of the CU's 160
 constexpr int kRankKeys = 64;
 constexpr int kRankThreads = 512;
 constexpr int kRankWaves = kRankThreads / 64;
@@ -612,13 +677,25 @@ template <int kMode>
 __device__ __forceinline__ int rank_count(const unsigned* s_sk, const unsigned* s_ix, int qa,
                                           const int qb, const unsigned mys, const unsigned myx) {
   int rank = 0;
+  // eight entries per round as 16-byte LDS reads (uniform address: broadcast).  Every caller's
+  // qa is a multiple of 8 whenever the range is not empty.
   for (; qa + 8 <= qb; qa += 8) {
+    const uint4 s0 = *reinterpret_cast<const uint4*>(s_sk + qa);
+    const uint4 s1 = *reinterpret_cast<const uint4*>(s_sk + qa + 4);
+    const unsigned sk8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    unsigned ix8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (kMode == 2) {
+      const uint4 i0 = *reinterpret_cast<const uint4*>(s_ix + qa);
+      const uint4 i1 = *reinterpret_cast<const uint4*>(s_ix + qa + 4);
+      ix8[0] = i0.x; ix8[1] = i0.y; ix8[2] = i0.z; ix8[3] = i0.w;
+      ix8[4] = i1.x; ix8[5] = i1.y; ix8[6] = i1.z; ix8[7] = i1.w;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const unsigned sk = s_sk[qa + u];
+      const unsigned sk = sk8[u];
       if (kMode == 0) rank += sk >= mys;
       if (kMode == 1) rank += sk > mys;
-      if (kMode == 2) rank += (((u64)sk << 32) | s_ix[qa + u]) > (((u64)mys << 32) | myx);
+      if (kMode == 2) rank += (((u64)sk << 32) | ix8[u]) > (((u64)mys << 32) | myx);
     }
   }
   for (; qa < qb; ++qa) {
@@ -630,12 +707,18 @@ __device__ __forceinline__ int rank_count(const unsigned* s_sk, const unsigned* 
   return rank;
 }
 
-__global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
-    u64* __restrict__ keys, int* __restrict__ counters, int batch, int cap, int key_stride,
-    int topk, SortSrc src, float4* __restrict__ sbox, int* __restrict__ slabel, int box_stride) {
-  __shared__ __attribute__((aligned(16))) unsigned s_sk[kRankMax];   // score half of the keys
-  __shared__ __attribute__((aligned(16))) unsigned s_ix[kRankMax];   // index half (~index)
-  __shared__ int s_lab[kRankMax];
+__host__ __device__ inline int rank_lds_keys(int cap) { return (cap + 63) & ~63; }
+__host__ __device__ inline size_t rank_lds_bytes(int cap) { return (size_t)rank_lds_keys(cap) * 12; }
+
+__global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict__ counters, int batch,
+                                                                 int cap, int topk, SortSrc src,
+                                                                 SortOut so) {
+  // dynamic LDS, sized by the list capacity: score halves of the keys, index halves (~index),
+  // labels
+  extern __shared__ __attribute__((aligned(16))) unsigned s_dyn[];
+  unsigned* s_sk = s_dyn;
+  unsigned* s_ix = s_dyn + rank_lds_keys(cap);
+  int* s_lab = reinterpret_cast<int*>(s_dyn + 2 * rank_lds_keys(cap));
   __shared__ int s_wsum[kRankWaves];
   __shared__ int s_part[kRankWaves][kRankKeys];
   // the image index is the fast grid dimension: blocks beyond an image's candidate count
@@ -645,6 +728,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p0 = blockIdx.y * kRankKeys;
+  RH_TL(0, 0);
   int found;
   if (src.from_tiles) {
     const TileCands tc = src.tc;
@@ -700,6 +784,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
       run += w < wave ? s_wsum[w] : 0;
       found += s_wsum[w];
     }
+    RH_TL(0, 1);
     if (p0 >= min(found, cap) && blockIdx.y != 0) return;   // nothing to rank here (block-uniform)
     for (int i0 = wb; i0 < we; i0 += 64 * kRankBatch) {
       int c[kRankBatch], lo[kRankBatch], base[kRankBatch];
@@ -765,6 +850,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
     }
   }
   __syncthreads();
+  RH_TL(0, 2);
   const int K = min(found, cap);
   const int ke = topk > 0 ? min(K, topk) : K;
   const int p = p0 + lane;
@@ -782,29 +868,53 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(
     rank += rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx);
   }
   s_part[wave][lane] = rank;
+  // The pair kernel ORs bits into the predecessor words: zero the words of the 64 ranks
+  // [p0, p0 + 64) (whichever keys end up there), words 0 .. p0/64, one 512-byte row per store.
+  if (p < ke)
+    for (int w = wave; w <= (int)blockIdx.y; w += kRankWaves)
+      so.mask[((size_t)j * so.wstride + w) * so.box_stride + p] = 0ull;
   __syncthreads();
+  RH_TL(0, 3);
   if (wave == 0) {
     rank = 0;
 #pragma unroll
     for (int w = 0; w < kRankWaves; ++w) rank += s_part[w][lane];
-    if (p < K && rank < ke) {
-      const size_t o = (size_t)j * box_stride + rank;
-      keys[(size_t)j * key_stride + rank] = ((u64)mys << 32) | (u64)myx;
-      const unsigned idx = 0xFFFFFFFFu - myx;
-      if (src.from_tiles) {
-        const unsigned n = idx - (unsigned)j * (unsigned)src.N;
-        sbox[o] = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
-                           src.height);
-      } else {
-        sbox[o] = src.boxes[idx];
+    const bool passed = p < K && rank < ke;      // else beyond the list, or cut by the top-k
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < K) {
+      const size_t q = (size_t)j * so.list_stride + p;
+      if (passed) {
+        const size_t o = (size_t)j * so.box_stride + rank;
+        so.keys[(size_t)j * so.key_stride + rank] = ((u64)mys << 32) | (u64)myx;
+        const unsigned idx = 0xFFFFFFFFu - myx;
+        if (src.from_tiles) {
+          const unsigned n = idx - (unsigned)j * (unsigned)src.N;
+          box = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
+                         src.height);
+        } else {
+          box = src.boxes[idx];
+        }
+        so.sbox[o] = box;
+        so.cbox[q] = box;
+        so.slabel[o] = s_lab[p];
+        for (int g = 0; g < so.nzw; ++g) so.nz[o * so.nzw + g] = 0ull;
       }
-      slabel[o] = s_lab[p];
+      so.cinfo[q] = make_int4(passed ? rank : -1, s_lab[p],
+                              __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
+    }
+    // this block's 64 list entries are one cluster of the pair kernel
+    const ClusterSummary cs = summarize_cluster(box, passed);
+    if (lane == 0) {
+      float4* out = so.csum + ((size_t)j * so.clusters + blockIdx.y) * 2;
+      out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
+      out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
     }
     if (blockIdx.y == 0 && lane == 0) {
       counters[j] = found;
       counters[batch + j] = max(found - cap, 0);
       counters[2 * batch + j] = ke;
     }
+    RH_TL(0, 4);
   }
 }
 
@@ -839,17 +949,14 @@ __global__ __launch_bounds__(kThreads) void sort_step_kernel(u64* __restrict__ k
     kj[l] = a;
   }
 }
-__global__ __launch_bounds__(kThreads) void sort_finish_kernel(
-    u64* __restrict__ keys, int* __restrict__ counters, int batch, int cap, int key_stride,
-    int topk, SortSrc src, float4* __restrict__ sbox, int* __restrict__ slabel, int box_stride) {
+__global__ __launch_bounds__(kThreads) void sort_finish_kernel(int* __restrict__ counters, int batch,
+                                                               int cap, int topk, SortSrc src,
+                                                               SortOut so) {
   const int j = blockIdx.y;
   const int i = blockIdx.x * kThreads + threadIdx.x;
   const int K = min(counters[j], cap);
   const int ke = topk > 0 ? min(K, topk) : K;
-  u64* kj = keys + (size_t)j * key_stride;
-  if (i < ke)
-    store_sorted(kj[i], i, j, src, kj, sbox + (size_t)j * box_stride,
-                 slabel + (size_t)j * box_stride);
+  if (i < ke) store_sorted(so.keys[(size_t)j * so.key_stride + i], i, j, src, so);
   if (i == 0) counters[2 * batch + j] = ke;
 }
 
@@ -945,124 +1052,294 @@ __global__ __launch_bounds__(kThreads) void nms_mask_general_kernel(const float4
 }
 
 // ---------------------------------------------------------------------------
-// The same bitmask for 0 < thresh, in as few vector instructions per pair as the test allows
-// (the mask stage is bound by vector ALU throughput, not by memory):
-//   w = min(x2, X2) - max(x1, X1); h likewise; inter = max(w, 0) * h   (h <= 0 gives inter <= 0)
-//   denom = max((area + AREA) - inter, 0)
-//   sure     = inter > denom * (thresh * (1 + 2^-21))   -> IoU > thresh for certain
-//   possible = inter > denom * (thresh * (1 - 2^-21))   -> cannot be excluded
-// inter > 0 implies both boxes have positive width and height and denom >= inter > 0, so the
-// clamp of denom only matters for degenerate boxes, where it makes both tests fail as they
-// must (IoU is then 0 or NaN).  possible & ~sure (a 2^-20 relative band around the threshold)
-// is settled afterwards with the exact division.  min / max are issued as single
-// instructions: the compiler would wrap each in NaN-quieting moves, more than doubling the
-// count.  Each test shifts its result into the lane's word through the carry
-// (word = 2 * word + test), walking the 32 boxes of a half-word from the highest down.
-// (Pairing two boxes per round so that the subtractions, products and sums become packed
-// float32 instructions cut the instruction count by 13 % and was slower: 21.6 against 19.4 us.)
+// Pair kernel (0 < thresh): finds the overlapping pairs without testing most pairs, and records
+// each as one bit of the later box's predecessor words.
+//
+// Boxes are grouped into CLUSTERS of 64 that are consecutive in list order (the order the
+// candidates had before sorting: ascending anchor index, i.e. neighbouring cells of one pyramid
+// level, similar sizes); the sort stage leaves each cluster's bounding box and area range.  Two
+// boxes can only have IoU > thresh > 0 if they intersect and if the smaller area is more than
+// thresh times the larger (the intersection is at most the smaller area, the union at least the
+// larger one; in float32 the computed quotient stays below min/max * (1 + 1e-6), and the test
+// here leaves a margin of 1e-4).  So:
+//   * a pair of clusters whose bounding boxes do not intersect, or whose area ranges are too far
+//     apart, is skipped as a whole (one compare per cluster pair, 64 cluster pairs per ballot);
+//   * inside a remaining pair (A, B) the wave holds A's boxes one per lane, loads B's boxes one
+//     per lane, and drops with ONE ballot every box of B that misses A's bounding box or area
+//     range; the survivors are broadcast from their lanes one at a time (v_readlane) and tested
+//     against the wave's 64 boxes:
+//       w = min(x2, X2) - max(x1, X1); h likewise; inter = max(w, 0) * h   (h <= 0 gives inter <= 0)
+//       denom = max((area + AREA) - inter, 0)
+//       possible = inter > (area + AREA) * thresh / (1 + thresh) * (1 - 2^-19)  -> IoU > thresh
+//                  cannot be excluded (inter > thresh * denom solved for inter, loosened)
+//       sure     = inter > denom * (thresh * (1 + 2^-21))   -> IoU > thresh for certain
+//     inter > 0 implies both boxes have positive width and height and denom >= inter > 0, so the
+//     clamp of denom only matters for degenerate boxes, where it makes the test fail as it must
+//     (IoU is then 0 or NaN).  min / max are single instructions (the compiler would wrap each
+//     in NaN-quieting moves).
+//   * possible & ~sure (a 2^-20 relative band around the threshold) is settled with the exact
+//     float32 division of torchvision's arithmetic.  All of it is symmetric in the two boxes, so
+//     every unordered pair is looked at once (cluster pairs A <= B; inside A == B the lower lane
+//     against the higher).
+// A hit sets bit (earlier rank % 64) of word (earlier rank / 64) of the LATER box by an atomic OR
+// (the sort stage zeroed the words) and raises that word's bit in the later box's nz bitmap.
+// Without spatial order in the list (a plain NMS call on shuffled boxes) every pair is tested, at
+// about the cost of a dense 64 x 64 tiling.
+// Grid clusters x slices x images: the waves of the `slices` blocks of cluster A share the
+// clusters B >= A that survive the cluster test, half a cluster pair at a time, round robin.
 // ---------------------------------------------------------------------------
-// word = 2 * word + (a > b)
-__device__ __forceinline__ void shift_in_gt(unsigned& word, const float a, const float b) {
-  asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-      : "+v"(word)
-      : "v"(a), "v"(b)
-      : "vcc");
+__device__ __forceinline__ float vmin_s(const float uniform, const float v) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(v));
+  return r;
+}
+__device__ __forceinline__ float vmax_s(const float uniform, const float v) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(v));
+  return r;
 }
 
-// (At most five waves per SIMD: 18.7 against 19.4 us with the seven its registers allow.)
+// One box of a cluster as a lane holds it.
+struct PairLane {
+  float4 box;
+  int rank;    // -1: no box here
+  int lab;
+  float area;
+};
+
 template <bool kPerClass>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 5))) void nms_mask_kernel(const float4* __restrict__ sbox,
-                                                            const int* __restrict__ slabel,
-                                                            const int* __restrict__ keff,
-                                                            u64* __restrict__ mask, int box_stride,
-                                                            int wstride, float thresh) {
-  __shared__ float4 s_box[kThreads / 64][64];
-  __shared__ float s_area[kThreads / 64][64];
-  __shared__ int s_lab[kThreads / 64][64];
-  const int j = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = keff[j];
-  const int W = (K + 63) >> 6;
-  const long long T = (long long)W * (W + 1) / 2;
-  const float4* bj = sbox + (size_t)j * box_stride;
-  const int* lj = kPerClass ? slabel + (size_t)j * box_stride : nullptr;
+__global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
+    const float4* __restrict__ cbox, const int4* __restrict__ cinfo,
+    const float4* __restrict__ csum, const int* __restrict__ counters, int batch,
+    u64* __restrict__ mask, u64* __restrict__ nz, int cap, int list_stride, int clusters,
+    int box_stride, int wstride, int nzw, int slices, float thresh, int ranked) {
+  // one-dimensional grid, the image index fastest: the workgroups of clusters beyond an image's
+  // list (most of the grid when the lists are far from full) come last and exit at once
+  const int j = blockIdx.x % batch;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int A = (int)(blockIdx.x / batch) / slices, slice = (int)(blockIdx.x / batch) % slices;
+  RH_TL(1, 0);
+  const float4* bj = cbox + (size_t)j * list_stride;
+  const int4* ij = cinfo + (size_t)j * list_stride;
+  const float4* sj = csum + (size_t)j * clusters * 2;
   u64* mj = mask + (size_t)j * box_stride * wstride;
-  const float c_hi = thresh * (1.0f + 4.8e-7f), c_lo = thresh * (1.0f - 4.8e-7f);
-  for (long long id = (long long)blockIdx.x * (kThreads / 64) + wave; id < T;
-       id += (long long)gridDim.x * (kThreads / 64)) {
-    // tile id -> (rt, ct) with rt <= ct; row rt of the triangle starts at rt*W - rt*(rt-1)/2
-    int rt = (int)(((2.0 * W + 1.0) - sqrt((2.0 * W + 1.0) * (2.0 * W + 1.0) - 8.0 * (double)id)) * 0.5);
-    rt = max(0, min(rt, W - 1));
-    while (rt > 0 && (long long)rt * W - (long long)rt * (rt - 1) / 2 > id) --rt;
-    while ((long long)(rt + 1) * W - (long long)(rt + 1) * rt / 2 <= id) ++rt;
-    const int ct = rt + (int)(id - ((long long)rt * W - (long long)rt * (rt - 1) / 2));
-    const int i = ct * 64 + lane;       // my box (the later one)
-    const int e = rt * 64 + lane;       // the earlier box this lane stages
-    const float4 mine = bj[min(i, K - 1)];
-    const int mylab = kPerClass ? lj[min(i, K - 1)] : 0;
-    {
-      const float4 eb = bj[min(e, K - 1)];
-      s_box[wave][lane] = eb;
-      s_area[wave][lane] = (eb.z - eb.x) * (eb.w - eb.y);
-      if (kPerClass) s_lab[wave][lane] = lj[min(e, K - 1)];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed
-    const float area = (mine.z - mine.x) * (mine.w - mine.y);
-    const int emax = min(64, K - rt * 64);
-    // earlier boxes only: bits below my own position in the diagonal tile, all bits otherwise
-    const u64 allowed = (rt == ct ? ((1ull << lane) - 1ull) : ~0ull) &
-                        (emax >= 64 ? ~0ull : ((1ull << emax) - 1ull));
-    unsigned sure_w[2], poss_w[2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      unsigned sw = 0u, pw = 0u;
-#pragma unroll 8
-      for (int cc = half * 32 + 31; cc >= half * 32; --cc) {
-        const float4 b = s_box[wave][cc];
-        const float w = vmin(mine.z, b.z) - vmax(mine.x, b.x);
-        const float h = vmin(mine.w, b.w) - vmax(mine.y, b.y);
-        float inter = vmax0(w) * h;
-        if (kPerClass) inter = s_lab[wave][cc] == mylab ? inter : -1.0f;
-        const float denom = vmax0((area + s_area[wave][cc]) - inter);
-        shift_in_gt(sw, inter, denom * c_hi);
-        shift_in_gt(pw, inter, denom * c_lo);
-      }
-      sure_w[half] = sw;
-      poss_w[half] = pw;
-    }
-    u64 sure = (((u64)sure_w[1] << 32) | sure_w[0]) & allowed;
-    u64 unsure = (((u64)poss_w[1] << 32) | poss_w[0]) & allowed & ~sure;
-    while (unsure) {                      // rare: exact division for the pairs inside the band
-      const int cc = __builtin_ctzll(unsure);
-      unsure &= unsure - 1ull;
-      const float4 b = s_box[wave][cc];
+  u64* nj = nz + (size_t)j * box_stride * nzw;
+  // My cluster's boxes and the summaries go out together with the counters (all inside their
+  // arrays whatever the counters say; what lies beyond the list is discarded below).
+  auto load_lane = [&](const int cluster) -> PairLane {
+    PairLane r;
+    const int q = min(cluster * 64 + lane, list_stride - 1);
+    r.box = bj[q];
+    const int4 info = ij[q];
+    r.rank = info.x;
+    r.lab = info.y;
+    r.area = __int_as_float(info.z);
+    return r;
+  };
+  PairLane me = load_lane(A);
+  const float4 a_box = sj[A * 2], a_rng = sj[A * 2 + 1];          // uniform
+  const int first_b = min(A + lane, clusters - 1);
+  const float4 b_box0 = sj[first_b * 2], b_rng0 = sj[first_b * 2 + 1];
+  __builtin_amdgcn_sched_barrier(0);
+  // ranked: the list is what the rank sort saw; else the boxes are in rank order themselves
+  const int klist = ranked ? min(counters[j], cap) : counters[2 * batch + j];
+  const int C = (klist + 63) >> 6;
+  RH_TL(1, 1);
+  if (A >= C) return;
+  if (A * 64 + lane >= klist) me.rank = -1;
+
+  const float f = fminf(thresh, 1.0f) * 0.9999f;
+  const float c_hi = thresh * (1.0f + 4.8e-7f);
+  const float k_filter = thresh / (1.0f + thresh) * (1.0f - 1.9e-6f);
+  const float4 mine = me.box;
+  const float area = me.area;
+  const bool valid = me.rank >= 0;
+  const u64 lanes_ok = __ballot(valid);
+  const int nwaves = slices * (kThreads / 64), mywave = slice * (kThreads / 64) + wave;
+
+  // lanes of `mine` that may overlap box b (record info) by more than thresh (almost always
+  // none).  The box is wave-uniform and sits in scalar registers.
+  auto possible = [&](const float4 b, const int4 info) -> u64 {
+    const float w = vmin_s(b.z, mine.z) - vmax_s(b.x, mine.x);
+    const float h = vmin_s(b.w, mine.w) - vmax_s(b.y, mine.y);
+    float inter = vmax0(w) * h;
+    if (kPerClass) inter = info.y == me.lab ? inter : -1.0f;
+    // inter > thresh * ((area + AREA) - inter), solved for inter and loosened by 2^-19 (this is
+    // only the filter: whatever passes is decided exactly below, and a pair that the exact test
+    // accepts passes here with room to spare)
+    return __ballot(inter > (area + __int_as_float(info.z)) * k_filter);
+  };
+  // decide and record the pairs (lane, box) of `hit`; src = the box's lane in cluster B
+  auto settle = [&](const float4 b, const int4 info, const int erank, const int src, const bool same,
+                    u64 hit) {
+    // inside one cluster each unordered pair once: only the lanes above the box's own
+    hit &= same ? lanes_ok & ~((2ull << src) - 1ull) : lanes_ok;
+    if (hit == 0ull) return;
+    if ((hit >> lane) & 1ull) {
       const float w = fmaxf(0.0f, fminf(mine.z, b.z) - fmaxf(mine.x, b.x));
       const float h = fmaxf(0.0f, fminf(mine.w, b.w) - fmaxf(mine.y, b.y));
       const float inter = w * h;
-      if (nms_hit_exact(inter, (area + s_area[wave][cc]) - inter, thresh)) sure |= 1ull << cc;
+      const float denom = (area + __int_as_float(info.z)) - inter;
+      // clear of the 2^-20 band around the threshold the product test is exact enough;
+      // inside it the float32 division of torchvision's arithmetic decides
+      bool sure = inter > fmaxf(denom, 0.0f) * c_hi;
+      if (__ballot(!sure) != 0ull) sure = sure || nms_hit_exact(inter, denom, thresh);
+      if (sure) {
+        const int brank = __builtin_amdgcn_readlane(erank, src);
+        const int first = min(me.rank, brank), later = max(me.rank, brank);
+        const int word = first >> 6;
+        atomicOr(&mj[(size_t)word * box_stride + later], 1ull << (first & 63));
+        atomicOr(&nj[(size_t)later * nzw + (word >> 6)], 1ull << (word & 63));
+      }
     }
-    if (i < K) mj[(size_t)rt * box_stride + i] = sure;
-    __builtin_amdgcn_wave_barrier();
+  };
+
+  int taken = 0;                                    // units seen so far
+  RH_TL(1, 2);
+  RH_TL_DO(int tl_tiles = 0, tl_surv = 0, tl_nset = 0; long long tl_a = 0, tl_t = 0, tl_set = 0;)
+  for (int b0 = A; b0 < C; b0 += 64) {
+    // ---- cluster test, 64 clusters per ballot (the first 64 summaries were requested up front)
+    const int bc = min(b0 + lane, C - 1);
+    const float4 b_box = b0 == A ? b_box0 : sj[bc * 2], b_rng = b0 == A ? b_rng0 : sj[bc * 2 + 1];
+    const bool apart_c = (b_box.z <= a_box.x) | (b_box.x >= a_box.z) | (b_box.w <= a_box.y) |
+                         (b_box.y >= a_box.w);
+    const bool off_c = (b_rng.x * f > a_rng.y) | (b_rng.y < a_rng.x * f);   // all too large / too small
+    u64 bm = __ballot(b0 + lane < C && !apart_c && !off_c);
+    // A unit of work is half a cluster pair (32 of B's boxes), dealt round robin over the waves
+    // of cluster A's workgroups.
+    u64 my_lo = 0ull, my_hi = 0ull;               // cluster pairs whose low / high half is mine
+    for (u64 t = bm; t != 0ull; t &= t - 1ull) {      // nwaves is a power of two
+      if ((taken & (nwaves - 1)) == mywave) my_lo |= t & (0ull - t);
+      if (((taken + 1) & (nwaves - 1)) == mywave) my_hi |= t & (0ull - t);
+      taken += 2;
+    }
+    u64 my_bm = my_lo | my_hi;
+    if (my_bm == 0ull) continue;
+    PairLane nxt = load_lane(b0 + __builtin_ctzll(my_bm));
+    while (my_bm != 0ull) {
+      const int bit = __builtin_ctzll(my_bm);
+      const int B = b0 + bit;
+      my_bm &= my_bm - 1ull;
+      const u64 halves = (((my_lo >> bit) & 1ull) ? 0x00000000FFFFFFFFull : 0ull) |
+                         (((my_hi >> bit) & 1ull) ? 0xFFFFFFFF00000000ull : 0ull);
+      const PairLane e = nxt;
+      if (my_bm != 0ull) nxt = load_lane(b0 + __builtin_ctzll(my_bm));   // on its way meanwhile
+      // B's boxes one per lane, only to find the ones worth testing: a box that misses A's
+      // bounding box or area range is out (a NaN coordinate is never culled, and never hits)
+      const bool apart = (e.box.z <= a_box.x) | (e.box.x >= a_box.z) | (e.box.w <= a_box.y) |
+                         (e.box.y >= a_box.w);
+      const bool off = (e.area * f > a_rng.y) | (e.area < a_rng.x * f);
+      const bool there = B * 64 + lane < klist && e.rank >= 0;
+      const u64 hm = __ballot(there && !apart && !off) & halves;
+      RH_TL_DO(++tl_tiles; tl_surv += __popcll(hm); tl_t = wall_clock64();)
+      // The survivors one at a time as wave-uniform values, broadcast from their lanes
+      // (v_readlane), four per round.  Measured alternatives: packing them into LDS and reading
+      // them back with 16-byte broadcast reads was bound by the LDS pipe, which all waves of a
+      // compute unit share (a broadcast read costs the bandwidth of 64 lanes); scalar loads of
+      // the same records, with or without glc, returned stale data now and then (records that an
+      // earlier call had left in the cache hierarchy), so they are not used for data that the
+      // kernel before has written.
+      for (u64 m = hm; m != 0ull;) {
+        int src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          src[u] = m != 0ull ? __builtin_ctzll(m) : src[u > 0 ? u - 1 : 0];   // past the last: repeat it
+          m &= m - 1ull;                                                      // 0 stays 0
+        }
+        float4 box[4];
+        int4 info[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          box[u] = make_float4(lane_value(e.box.x, src[u]), lane_value(e.box.y, src[u]),
+                               lane_value(e.box.z, src[u]), lane_value(e.box.w, src[u]));
+          info[u] = make_int4(0, kPerClass ? __builtin_amdgcn_readlane(e.lab, src[u]) : 0,
+                              __builtin_amdgcn_readlane(__float_as_int(e.area), src[u]), 0);
+        }
+        u64 h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h[u] = possible(box[u], info[u]);
+        if ((h[0] | h[1] | h[2] | h[3]) != 0ull) {
+          RH_TL_DO(const long long tl_s = wall_clock64(); ++tl_nset;)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) settle(box[u], info[u], e.rank, src[u], B == A, h[u]);
+          RH_TL_DO(tl_set += wall_clock64() - tl_s;)
+        }
+      }
+      RH_TL_DO(tl_a += wall_clock64() - tl_t;)
+    }
+  }
+  RH_TL(1, 3);
+  RH_TL_VALUE(1, 4, tl_tiles);
+  RH_TL_VALUE(1, 5, tl_surv);
+  RH_TL_VALUE(1, 6, tl_a);
+  RH_TL_VALUE(1, 7, tl_set * 1000 + tl_nset);
+}
+
+// Cluster summaries, list records and zeroed mask words for sort paths that do not provide them
+// (lists beyond the rank sort's capacity): clusters are 64 consecutive ranks.  Grid (clusters,
+// images), one wave per cluster.
+__global__ __launch_bounds__(64) void cluster_prepare_kernel(const float4* __restrict__ sbox,
+                                                             const int* __restrict__ slabel,
+                                                             const int* __restrict__ keff,
+                                                             float4* __restrict__ csum,
+                                                             int4* __restrict__ cinfo,
+                                                             u64* __restrict__ mask, int box_stride,
+                                                             int wstride, int clusters) {
+  const int j = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  const int K = keff[j];
+  if (g * 64 >= K) return;
+  const int i = g * 64 + lane;
+  const float4 box = sbox[(size_t)j * box_stride + min(i, K - 1)];
+  const ClusterSummary cs = summarize_cluster(box, i < K);
+  if (lane == 0) {
+    float4* out = csum + ((size_t)j * clusters + g) * 2;
+    out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
+    out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
+  }
+  if (i < K) {
+    cinfo[(size_t)j * box_stride + i] =
+        make_int4(i, slabel[(size_t)j * box_stride + i],
+                  __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
+    for (int w = 0; w <= g; ++w) mask[((size_t)j * wstride + w) * box_stride + i] = 0ull;
+  }
+}
+
+// nz bitmap for the dense mask kernel: every word up to the box's own chunk may be non-zero.
+__global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restrict__ keff,
+                                                            u64* __restrict__ nz, int box_stride,
+                                                            int nzw) {
+  const int j = blockIdx.y;
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= keff[j]) return;
+  const int last = i >> 6;                               // words 0 .. last
+  for (int g = 0; g < nzw; ++g) {
+    const int lo = g * 64;
+    u64 bits = 0ull;
+    if (last >= lo + 63) bits = ~0ull;
+    else if (last >= lo) bits = (2ull << (last - lo)) - 1ull;
+    nz[((size_t)j * box_stride + i) * nzw + g] = bits;
   }
 }
 
 // ---------------------------------------------------------------------------
-// Greedy sweep: one workgroup of kSweepWaves waves per image walks the sorted boxes in
-// chunks of 64; wave s owns the chunks c = s, s + kSweepWaves, ...  Lane l of chunk c owns
-// box c*64+l.  A chunk is resolved in two parts:
-//   * bulk, off the critical path: AND the box's predecessor words of all earlier chunks with
-//     those chunks' kept bitmaps as they get published (the loads do not depend on anything
-//     and are issued up front, a batch at a time; the other waves resolve the chunks in
-//     between meanwhile);
-//   * tail, the serial chain: once chunk c-1 is published, one ballot tells which boxes are
-//     already suppressed, and the chunk's diagonal word resolves the boxes that overlap an
-//     earlier box of the same chunk.
-// Kept bitmaps, running totals and the "chunks done" counter live in LDS; waves wait on the
-// counter (release / acquire at workgroup scope), never on a barrier, so each chunk costs
-// one short hand-over instead of a memory latency.
+// Resolve kernel: which boxes survive the greedy pass, from the sparse predecessor words.
+// Box i is dropped iff a KEPT box that precedes it overlaps it.  One workgroup per image keeps two
+// bitmaps over the boxes in LDS, `lo` (surely kept) and `hi` (possibly kept), starting from
+// lo = nothing, hi = everything, and every round each open box looks at its predecessor words:
+//   a predecessor in lo  -> the box is dropped (leaves hi);
+//   no predecessor in hi -> the box is kept (enters lo).
+// lo only grows and hi only shrinks, lo <= kept <= hi holds throughout, and a round settles at
+// least every box whose predecessors are settled (the first open box always is one), so the
+// loop ends with lo == hi == the greedy result after as many rounds as the longest chain of
+// undecided overlaps is deep -- a handful in practice, against one serial step per 64 boxes for
+// a sweep in rank order.  A box without predecessor words (three in four) is kept in the first
+// round.  Lane l of wave v handles boxes (s*16 + v)*64 + l, s = 0, 1, ..: a wave's ballot over a
+// slot is that chunk's bitmap word.  With kSlots > 0 a thread has at most kSlots boxes and
+// keeps the first two predecessor words of each in registers (boxes with more re-read the rest
+// from memory each round); kSlots == 0 handles any number of boxes without that cache.
 // Outputs either the kept original indices (keep_idx, for rh_nms) or the
-// (score, label, box) triples of model.py:338-340.
+// (score, label, box) triples of model.py:338-340, in rank order.
 // ---------------------------------------------------------------------------
 struct SweepOut {
   long long* keep_idx;   // [B][out_stride] or null
@@ -1078,131 +1355,220 @@ struct SweepOut {
   int batch;
 };
 
-constexpr int kSweepWaves = 16;
-constexpr int kSweepBatch = 32;   // predecessor words loaded together
-constexpr int kSweepSpinLimit = 1 << 22;
+constexpr int kResolveWaves = 16;
+constexpr int kResolveThreads = 64 * kResolveWaves;
 
-__host__ __device__ inline size_t sweep_lds_bytes(int wstride) {
-  return (size_t)wstride * sizeof(u64) + ((size_t)wstride + 3) * sizeof(int);
+__host__ __device__ inline size_t resolve_lds_bytes(int wstride) {
+  return (size_t)wstride * 2 * sizeof(u64) + ((size_t)wstride + 1) * sizeof(int);
 }
 
-// Waits until chunk w of this image is published (*s_done > w); `seen` caches the last value
-// read.  Chunk w is published by another wave of this workgroup, which never waits for a
-// later chunk, so the wait always ends; the bound only keeps a logic error from hanging the
-// device (the image's count is then reported as -1).
-__device__ __forceinline__ void wait_published(int* s_done, int* s_fail, const int w, const int W,
-                                               int& seen) {
-  for (int spin = 0; seen <= w; ++spin) {
-    seen = __builtin_amdgcn_readfirstlane(
-        __hip_atomic_load(s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-    if (seen > w) break;
-    if (spin > kSweepSpinLimit) {
-      *s_fail = 1;
-      seen = W;
-      break;
+// A box's predecessor words as the cached form holds them.
+struct BoxPreds {
+  u64 w0, w1;      // first two predecessor words (0 when absent)
+  int i0, i1;      // their word indices (0 when absent)
+  bool more;       // further words exist: those are read from memory every round
+};
+
+// Bits of mask word w that can belong to box `row`: boxes that precede it in rank.  The pair
+// kernel only sets such bits; masking them here as well means that whatever the words hold, the
+// relation the rounds work on has no cycle, so the rounds always end.
+__device__ __forceinline__ u64 earlier_bits(const int w, const int row) {
+  const int c = row >> 6;
+  return w < c ? ~0ull : (w == c ? (1ull << (row & 63)) - 1ull : 0ull);
+}
+
+// Is a predecessor of box `row` surely kept (d != 0) / possibly kept (m != 0)?  Walks the box's
+// non-zero words beyond the first `skip` of them, eight loads in flight at a time, and stops as
+// soon as the box is known to be dropped.
+__device__ __forceinline__ void scan_words(const u64* s_lo, const u64* s_hi,
+                                           const u64* __restrict__ nzrow, const int nzw,
+                                           const u64* __restrict__ mj, const int box_stride,
+                                           const int row, int skip, u64& d, u64& m) {
+  for (int g = 0; g < nzw && d == 0ull; ++g) {
+    u64 bits = nzrow[g];
+    for (; skip > 0 && bits != 0ull; --skip) bits &= bits - 1ull;
+    while (bits != 0ull && d == 0ull) {
+      int w[8];
+      u64 word[8];
+      int n = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool has = bits != 0ull;
+        w[u] = has ? g * 64 + __builtin_ctzll(bits) : (u > 0 ? w[u - 1] : 0);
+        n += has;
+        bits &= bits - 1ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) word[u] = mj[(size_t)w[u] * box_stride + row];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < n) {
+          const u64 pw = word[u] & earlier_bits(w[u], row);
+          d |= pw & s_lo[w[u]];
+          m |= pw & s_hi[w[u]];
+        }
+      }
     }
-    __builtin_amdgcn_s_sleep(1);
   }
 }
 
-__global__ __launch_bounds__(64 * kSweepWaves) void nms_sweep_kernel(
+template <int kSlots>
+__global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
     const u64* __restrict__ keys, const float4* __restrict__ sbox, const int* __restrict__ slabel,
-    const int* __restrict__ keff, const u64* __restrict__ mask, int key_stride, int box_stride,
-    int wstride, SweepOut o) {
-  extern __shared__ __attribute__((aligned(16))) u64 s_kept[];   // [wstride] kept bitmap per chunk
-  int* s_total = reinterpret_cast<int*>(s_kept + wstride);        // [wstride + 1] kept before chunk c
-  int* s_done = s_total + wstride + 1;                            // chunks published so far
-  int* s_fail = s_done + 1;                                       // a wait gave up (never expected)
+    const int* __restrict__ keff, const u64* __restrict__ mask, const u64* __restrict__ nz,
+    int key_stride, int box_stride, int wstride, int nzw, SweepOut o) {
+  extern __shared__ __attribute__((aligned(16))) u64 s_lo[];      // [wstride] surely kept
+  u64* s_hi = s_lo + wstride;                                     // [wstride] possibly kept
+  int* s_total = reinterpret_cast<int*>(s_hi + wstride);          // [wstride + 1] kept before chunk c
   const int j = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  RH_TL(2, 0);
   const int K = keff[j];
   const int W = (K + 63) >> 6;
   const u64* kj = keys + (size_t)j * key_stride;
   const float4* bj = sbox + (size_t)j * box_stride;
   const int* lj = slabel ? slabel + (size_t)j * box_stride : nullptr;
   const u64* mj = mask + (size_t)j * box_stride * wstride;
-  // always-loadable label source (the keys' low words when there are no labels; value unused)
-  const int* lsafe = lj ? lj : reinterpret_cast<const int*>(kj);
+  const u64* nj = nz + (size_t)j * box_stride * nzw;
   if (threadIdx.x == 0) {
-    s_total[0] = 0;
-    *s_done = 0;
-    *s_fail = 0;
-    if (W == 0) o.count[j] = 0;
     if (o.cand_out) o.cand_out[j] = o.counters[j];
     if (o.ovf_out) o.ovf_out[j] = o.counters[o.batch + j];
   }
+  constexpr int kCached = kSlots > 0 ? kSlots : 1;
+  const int nslots = kSlots > 0 ? kSlots : (W + kResolveWaves - 1) / kResolveWaves;
+
+  // ---- start: lo = nothing, hi = every box
+  for (int s = 0; s < nslots; ++s) {
+    const int c = s * kResolveWaves + wave;
+    if (c < W && lane == 0) {
+      const int left = K - c * 64;
+      s_lo[c] = 0ull;
+      s_hi[c] = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    }
+  }
+  // ---- cached form (one nz word per box: at most 64 words): the nz words of all slots go out
+  // together, then the first two predecessor words of every box, unconditionally (indices
+  // clamped into the mask; a word that is not there is loaded from word 0 and discarded)
+  BoxPreds pr[kCached];
+  u64 okey[kCached];        // what the outputs need, requested now and used after the rounds
+  float4 obox[kCached];
+  int olab[kCached];
+  if (kSlots > 0) {
+    u64 bits[kCached];
+#pragma unroll
+    for (int s = 0; s < kCached; ++s) {
+      const int c = s * kResolveWaves + wave;
+      const int row = min(c * 64 + lane, max(K - 1, 0));
+      bits[s] = nj[(size_t)row * nzw];
+      okey[s] = kj[row];
+      obox[s] = bj[row];
+      olab[s] = lj ? lj[row] : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < kCached; ++s) {
+      const int c = s * kResolveWaves + wave;
+      const int row = min(c * 64 + lane, max(K - 1, 0));
+      const bool live = c < W && c * 64 + lane < K;
+      u64 b = live ? bits[s] : 0ull;
+      // a box without predecessor words is kept: the first round is done here
+      const u64 free_now = __ballot(live && b == 0ull);
+      if (c < W && lane == 0) s_lo[c] = free_now;
+      const bool has0 = b != 0ull;
+      pr[s].i0 = has0 ? __builtin_ctzll(b) : 0;
+      b &= b - 1ull;
+      const bool has1 = b != 0ull;
+      pr[s].i1 = has1 ? __builtin_ctzll(b) : 0;
+      b &= b - 1ull;
+      pr[s].more = b != 0ull;
+      const u64 x = mj[(size_t)pr[s].i0 * box_stride + row];
+      const u64 y = mj[(size_t)pr[s].i1 * box_stride + row];
+      pr[s].w0 = has0 ? x & earlier_bits(pr[s].i0, c * 64 + lane) : 0ull;
+      pr[s].w1 = has1 ? y & earlier_bits(pr[s].i1, c * 64 + lane) : 0ull;
+    }
+  }
   __syncthreads();
-  int seen = 0;   // last value of *s_done this wave has observed
-  for (int c = wave; c < W; c += kSweepWaves) {
-    // Every load is unconditional (row and word indices clamped into the written part of the
-    // mask; rows >= K are discarded by live_rows below) and issued ahead of its first use.
-    const int row = min(c * 64 + lane, K - 1);
-    const u64 diag = mj[(size_t)c * box_stride + row];   // earlier boxes of this chunk that overlap me
-    const u64 key = kj[row];
-    const int lab = lsafe[row];
-    const float4 box = bj[row];
-    // the two chunks right before mine are published last: their words get registers of
-    // their own, so the hand-over path below does not run through the unrolled chain
-    const u64 last1 = mj[(size_t)max(c - 1, 0) * box_stride + row];
-    const u64 last2 = mj[(size_t)max(c - 2, 0) * box_stride + row];
-    u64 acc = 0ull;
-    const int cb = c - 2;   // chunks [0, cb) go through the batches
-    for (int w0 = 0; w0 < cb; w0 += kSweepBatch) {
-      u64 word[kSweepBatch];
-#pragma unroll
-      for (int u = 0; u < kSweepBatch; ++u) word[u] = mj[(size_t)min(w0 + u, c) * box_stride + row];
-      __builtin_amdgcn_sched_barrier(0);          // keep all loads ahead of the first use
-      // words of chunks already published: plain LDS reads, no waiting in between
-      seen = max(seen, __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                           s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)));
-      const int ready = min(seen, cb);
-#pragma unroll
-      for (int u = 0; u < kSweepBatch; ++u)
-        if (w0 + u < ready) acc |= word[u] & s_kept[w0 + u];
-      // the rest as they get published
-#pragma unroll
-      for (int u = 0; u < kSweepBatch; ++u) {
-        const int w = w0 + u;
-        if (w >= ready && w < cb) {
-          wait_published(s_done, s_fail, w, W, seen);
-          acc |= word[u] & s_kept[w];
-        }
+
+  // one round of one chunk; returns whether the chunk still has open boxes
+  auto round_of = [&](const int c, const BoxPreds& p) -> bool {
+    const u64 lo = s_lo[c], hi = s_hi[c];
+    const u64 open = hi & ~lo;
+    if (open == 0ull) return false;               // wave-uniform: this chunk is settled
+    const bool mine_open = (open >> lane) & 1ull;
+    u64 d = 0ull, m = 0ull;
+    if (mine_open) {
+      const int row = c * 64 + lane;
+      if (kSlots > 0) {
+        d = (p.w0 & s_lo[p.i0]) | (p.w1 & s_lo[p.i1]);
+        m = (p.w0 & s_hi[p.i0]) | (p.w1 & s_hi[p.i1]);
+        if (p.more && d == 0ull)
+          scan_words(s_lo, s_hi, nj + (size_t)row * nzw, nzw, mj, box_stride, row, 2, d, m);
+      } else {
+        scan_words(s_lo, s_hi, nj + (size_t)row * nzw, nzw, mj, box_stride, row, 0, d, m);
       }
     }
-    if (c >= 2) {
-      wait_published(s_done, s_fail, c - 2, W, seen);
-      acc |= last2 & s_kept[c - 2];
-    }
-    if (c >= 1) {
-      wait_published(s_done, s_fail, c - 1, W, seen);
-      acc |= last1 & s_kept[c - 1];
-    }
-    const int left = K - c * 64;
-    const u64 live_rows = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-    const u64 alive = ~__ballot(acc != 0ull) & live_rows;
-    // Inside the chunk a box is dropped iff an earlier KEPT box of the chunk overlaps it.
-    // Bracket the kept set between `lo` (surely kept) and `hi` (possibly kept) and tighten
-    // both with one ballot each until they meet; every round settles at least the first open
-    // box, and in practice the chains are a few boxes deep, so this takes 2-4 rounds instead
-    // of one scalar step per overlapping box.
-    u64 lo = alive & ~__ballot(diag != 0ull), hi = alive;
-    while (lo != hi) {
-      const u64 nlo = alive & ~__ballot((diag & hi) != 0ull);
-      const u64 nhi = alive & ~__ballot((diag & lo) != 0ull);
-      lo = nlo;
-      hi = nhi;
-    }
-    const u64 kept = lo;
-    const int before = s_total[c];                 // published together with chunk c-1
+    const u64 now_kept = __ballot(mine_open && m == 0ull);      // no predecessor can still be kept
+    const u64 now_dropped = __ballot(mine_open && d != 0ull);   // a predecessor is surely kept
+    const u64 nlo = lo | now_kept, nhi = hi & ~now_dropped;
     if (lane == 0) {
-      s_kept[c] = kept;
-      s_total[c + 1] = before + __popcll(kept);
-      __hip_atomic_store(s_done, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      s_lo[c] = nlo;
+      s_hi[c] = nhi;
     }
-    // ---- outputs, after the hand-over
+    return (nhi & ~nlo) != 0ull;
+  };
+
+  // ---- rounds
+  RH_TL(2, 1);
+  RH_TL_DO(int tl_rounds = 0;)
+  bool gave_up = false;
+  for (int round = 0;; ++round) {
+    RH_TL_DO(++tl_rounds;)
+    // every round settles at least the first open box, so K rounds always suffice; the bound
+    // only keeps a logic error from hanging the device (the image's count is then -1)
+    if (round > K + 1) {
+      gave_up = true;
+      break;
+    }
+    int open_any = 0;
+    if (kSlots > 0) {
+#pragma unroll
+      for (int s = 0; s < kCached; ++s) {
+        const int c = s * kResolveWaves + wave;
+        if (c < W) open_any |= round_of(c, pr[s]);
+      }
+    } else {
+      for (int c = wave; c < W; c += kResolveWaves) open_any |= round_of(c, pr[0]);
+    }
+    if (!__syncthreads_or(open_any)) break;
+  }
+
+  // ---- kept boxes before each chunk (wave 0), then the outputs
+  RH_TL(2, 2);
+  RH_TL_VALUE(2, 5, tl_rounds);
+  if (wave == 0) {
+    int run = 0;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+      const int c = c0 + lane;
+      const int n = c < W ? __popcll(s_lo[c]) : 0;
+      int incl = n;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const int t = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += t;
+      }
+      if (c < W) s_total[c] = run + incl - n;
+      run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+      s_total[W] = run;
+      o.count[j] = gave_up ? -1 : min(run, o.max_keep);
+    }
+  }
+  __syncthreads();
+  auto emit = [&](const int c, const u64 key, const float4 box, const int lab) {
+    const u64 kept = s_lo[c];
     if ((kept >> lane) & 1ull) {
-      const int pos = before + __popcll(kept & ((1ull << lane) - 1ull));
+      const int pos = s_total[c] + __popcll(kept & ((1ull << lane) - 1ull));
       if (pos < o.max_keep) {
         const size_t at = (size_t)j * o.out_stride + pos;
         if (o.keep_idx) o.keep_idx[at] = (long long)key_index(key);
@@ -1211,9 +1577,20 @@ __global__ __launch_bounds__(64 * kSweepWaves) void nms_sweep_kernel(
         if (o.boxes) o.boxes[at] = box;
       }
     }
-    if (c == W - 1 && lane == 0)
-      o.count[j] = *s_fail ? -1 : min(before + __popcll(kept), o.max_keep);
+  };
+  if (kSlots > 0) {
+#pragma unroll
+    for (int s = 0; s < kCached; ++s) {
+      const int c = s * kResolveWaves + wave;
+      if (c < W) emit(c, okey[s], obox[s], olab[s]);
+    }
+  } else {
+    for (int c = wave; c < W; c += kResolveWaves) {
+      const int row = min(c * 64 + lane, K - 1);
+      emit(c, kj[row], bj[row], lj ? lj[row] : 0);
+    }
   }
+  RH_TL(2, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -1235,13 +1612,16 @@ static BoxCoder make_coder(const float* mean, const float* std) {
   return bc;
 }
 
-// Buffer geometry of sort + mask + sweep over B candidate lists.
+// Buffer geometry of sort + pair + resolve over B candidate lists.
 struct NmsPlan {
   int batch;
   int cap;          // candidates per image the key buffers hold
   int key_stride;   // >= next_pow2(cap), >= 64
-  int box_cap;      // boxes that reach the mask stage (min(cap, topk))
+  int box_cap;      // boxes that reach the NMS (min(cap, topk))
   int wstride;      // mask words per box
+  int nzw;          // words of a box's bitmap of non-zero mask words
+  bool ranked;      // the rank sort runs: list-order arrays exist
+  int clusters;     // clusters of 64 list entries (ranked) or 64 ranks (not ranked)
 };
 
 static NmsPlan make_plan(int batch, long long cap, int topk) {
@@ -1252,7 +1632,18 @@ static NmsPlan make_plan(int batch, long long cap, int topk) {
   p.box_cap = (topk > 0 && topk < cap) ? topk : (int)cap;
   if (p.box_cap < 1) p.box_cap = 1;
   p.wstride = (p.box_cap + 63) / 64;
+  p.nzw = (p.wstride + 63) / 64;
+  p.ranked = p.cap <= kRankMax;
+  p.clusters = ((p.ranked ? p.cap : p.box_cap) + 63) / 64;
   return p;
+}
+
+// Limits of the NMS stages, checked before anything is launched.
+static int check_plan(const NmsPlan& p) {
+  RH_REQUIRE(resolve_lds_bytes(p.wstride) <= 160 * 1024, RH_ESHAPE,
+             "%d boxes per image exceed the LDS bitmaps of the NMS (at most %d): lower cand_cap or "
+             "set pre_nms_topk", p.box_cap, (int)((160 * 1024 - 4) / 20) * 64);
+  return RH_OK;
 }
 
 struct PostWorkspace {
@@ -1263,7 +1654,11 @@ struct PostWorkspace {
   int* counters;     // [3][B]: candidates found, dropped, passed to NMS (written every call)
   float4* sbox;
   int* slabel;
-  u64* mask;
+  u64* mask;         // [B][wstride][box_cap] predecessor words; only non-zero words are written
+  u64* nz;           // [B][box_cap][nzw] which words those are
+  float4* cbox;      // [B][cap] boxes in list order (rank sort only)
+  int4* cinfo;       // [B][cap] (rank or -1, label) in list order (rank sort only)
+  float4* csum;      // [B][clusters][2] bounding box and area range of each cluster
   size_t bytes;
 };
 
@@ -1278,16 +1673,50 @@ static PostWorkspace carve_post(void* ws, const NmsPlan& p, long long num_tiles)
   w.sbox = cv.take<float4>((size_t)p.batch * p.box_cap);
   w.slabel = cv.take<int>((size_t)p.batch * p.box_cap);
   w.mask = cv.take<u64>((size_t)p.batch * p.box_cap * p.wstride);
+  w.nz = cv.take<u64>((size_t)p.batch * p.box_cap * p.nzw);
+  w.cbox = cv.take<float4>(p.ranked ? (size_t)p.batch * p.cap : 0);
+  w.cinfo = cv.take<int4>((size_t)p.batch * (p.ranked ? p.cap : p.box_cap));
+  w.csum = cv.take<float4>((size_t)p.batch * p.clusters * 2);
   w.bytes = cv.off;
   return w;
 }
 
+static SortOut sort_out(const NmsPlan& p, const PostWorkspace& w) {
+  SortOut so;
+  so.keys = w.keys;
+  so.sbox = w.sbox;
+  so.slabel = w.slabel;
+  so.nz = w.nz;
+  so.cbox = p.ranked ? w.cbox : nullptr;
+  so.cinfo = w.cinfo;
+  so.csum = w.csum;
+  so.mask = w.mask;
+  so.key_stride = p.key_stride;
+  so.box_stride = p.box_cap;
+  so.list_stride = p.cap;
+  so.nzw = p.nzw;
+  so.wstride = p.wstride;
+  so.clusters = p.clusters;
+  return so;
+}
+
+// Kernels that use more dynamic LDS than the default limit must opt in.
+template <typename Kernel>
+static int allow_lds(Kernel kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return RH_OK;
+}
+
 static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const SortSrc& src,
                        hipStream_t s) {
-  if (p.cap <= kRankMax) {
+  const SortOut so = sort_out(p, w);
+  if (p.ranked) {
+    const size_t lds = rank_lds_bytes(p.cap);
+    if (int e = allow_lds(sort_rank_kernel, lds)) return e;
     hipLaunchKernelGGL(sort_rank_kernel, dim3(p.batch, (p.cap + kRankKeys - 1) / kRankKeys),
-                       dim3(kRankThreads), 0, s, w.keys, w.counters, p.batch, p.cap, p.key_stride,
-                       topk, src, w.sbox, w.slabel, p.box_cap);
+                       dim3(kRankThreads), lds, s, w.counters, p.batch, p.cap, topk, src, so);
     RH_CHECK_LAUNCH("sort_rank_kernel");
     return RH_OK;
   }
@@ -1298,12 +1727,9 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
   }
   if (p.key_stride <= kLdsSortMax) {
     const size_t lds = (size_t)p.key_stride * sizeof(u64) + 16;
-    if (lds > 48 * 1024)   // above the default dynamic-LDS limit the kernel must opt in
-      RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_lds_kernel, dim3(p.batch), dim3(kSortThreads), lds, s, w.keys,
-                       w.counters, p.batch, p.cap, p.key_stride, topk, src, w.sbox, w.slabel,
-                       p.box_cap);
+    if (int e = allow_lds(sort_lds_kernel, lds)) return e;
+    hipLaunchKernelGGL(sort_lds_kernel, dim3(p.batch), dim3(kSortThreads), lds, s, w.counters, p.batch,
+                       p.cap, topk, src, so);
     RH_CHECK_LAUNCH("sort_lds_kernel");
     return RH_OK;
   }
@@ -1315,40 +1741,61 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
     for (int jj = k >> 1; jj > 0; jj >>= 1)
       hipLaunchKernelGGL(sort_step_kernel, gh, dim3(kThreads), 0, s, w.keys, p.key_stride, P, k, jj);
   hipLaunchKernelGGL(sort_finish_kernel, dim3((p.box_cap + kThreads - 1) / kThreads, p.batch),
-                     dim3(kThreads), 0, s, w.keys, w.counters, p.batch, p.cap, p.key_stride, topk,
-                     src, w.sbox, w.slabel, p.box_cap);
+                     dim3(kThreads), 0, s, w.counters, p.batch, p.cap, topk, src, so);
   RH_CHECK_LAUNCH("global bitonic sort");
   return RH_OK;
 }
 
 static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, int per_class,
                       SweepOut out, hipStream_t s) {
+  if (int e = check_plan(p)) return e;
   const int* keff = w.counters + 2 * p.batch;
-  const long long tiles = (long long)p.wstride * (p.wstride + 1) / 2;
-  long long gx = (tiles + 3) / 4;
-  if (gx > 2048) gx = 2048;
-  if (gx < 1) gx = 1;
   if (thresh > 0.0f && thresh < 1e30f) {
-    auto kern = per_class ? nms_mask_kernel<true> : nms_mask_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, p.batch), dim3(kThreads), 0, s, w.sbox,
-                       per_class ? w.slabel : nullptr, keff, w.mask, p.box_cap, p.wstride, thresh);
+    if (!p.ranked) {
+      hipLaunchKernelGGL(cluster_prepare_kernel, dim3(p.clusters, p.batch), dim3(64), 0, s, w.sbox,
+                         w.slabel, keff, w.csum, w.cinfo, w.mask, p.box_cap, p.wstride, p.clusters);
+      RH_CHECK_LAUNCH("cluster_prepare_kernel");
+    }
+    // `slices` blocks (4 waves each) share the cluster pairs of one cluster
+    int slices = 1;                                   // a power of two (the kernel masks with it)
+    while (slices < 8 && slices * 64 <= p.clusters) slices *= 2;
+    RH_REQUIRE((long long)p.clusters * slices * p.batch < (1ll << 31), RH_ESHAPE, "too many NMS workgroups");
+    auto kern = per_class ? nms_pairs_kernel<true> : nms_pairs_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.clusters * slices * p.batch)), dim3(kThreads), 0, s,
+                       p.ranked ? w.cbox : w.sbox, w.cinfo, w.csum, w.counters, p.batch, w.mask, w.nz,
+                       p.cap, p.ranked ? p.cap : p.box_cap, p.clusters, p.box_cap, p.wstride, p.nzw,
+                       slices, thresh, p.ranked ? 1 : 0);
+    RH_CHECK_LAUNCH("nms_pairs_kernel");
   } else {
+    // thresh <= 0 (or not a number): every pair may count, the dense mask is the right form
+    const long long tiles = (long long)p.wstride * (p.wstride + 1) / 2;
+    long long gx = (tiles + 3) / 4;
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(nms_mask_general_kernel, dim3((unsigned)gx, p.batch), dim3(kThreads), 0, s,
                        w.sbox, per_class ? w.slabel : nullptr, keff, w.mask, p.box_cap, p.wstride,
                        thresh, per_class);
+    hipLaunchKernelGGL(nz_dense_kernel, dim3((p.box_cap + kThreads - 1) / kThreads, p.batch),
+                       dim3(kThreads), 0, s, keff, w.nz, p.box_cap, p.nzw);
+    RH_CHECK_LAUNCH("nms_mask_general_kernel");
   }
-  RH_CHECK_LAUNCH("nms_mask_kernel");
-  const size_t lds = sweep_lds_bytes(p.wstride);
-  RH_REQUIRE(lds <= 160 * 1024, RH_ESHAPE, "%d boxes per image exceed the sweep's LDS bitmap",
-             p.box_cap);
-  if (lds > 48 * 1024)
-    RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(nms_sweep_kernel, dim3(p.batch), dim3(64 * kSweepWaves), lds, s, w.keys, w.sbox,
-                     w.slabel, keff, w.mask, p.key_stride, p.box_cap, p.wstride, out);
-  RH_CHECK_LAUNCH("nms_sweep_kernel");
+  const size_t lds = resolve_lds_bytes(p.wstride);
+  auto kern = p.box_cap <= 1024   ? nms_resolve_kernel<1>
+              : p.box_cap <= 2048 ? nms_resolve_kernel<2>
+              : p.box_cap <= 4096 ? nms_resolve_kernel<4>
+                                  : nms_resolve_kernel<0>;
+  if (int e = allow_lds(kern, lds)) return e;
+  hipLaunchKernelGGL(kern, dim3(p.batch), dim3(kResolveThreads), lds, s, w.keys, w.sbox, w.slabel, keff,
+                     w.mask, w.nz, p.key_stride, p.box_cap, p.wstride, p.nzw, out);
+  RH_CHECK_LAUNCH("nms_resolve_kernel");
   return RH_OK;
 }
+
+#ifdef RH_TIMELINE
+extern "C" int rh_tl_read(long long* out, size_t count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rh_tl), count * sizeof(long long));
+}
+#endif
 
 }  // namespace rh
 
@@ -1417,6 +1864,7 @@ int rh_nms(const float* boxes, const float* scores, const int32_t* labels, int64
   RH_REQUIRE(boxes && scores && keep, RH_EINVAL, "null pointer");
   RH_REQUIRE(aligned16(boxes), RH_EALIGN, "boxes must be 16-byte aligned");
   const NmsPlan p = make_plan(1, k, 0);
+  if (int e = check_plan(p)) return e;
   const size_t need = carve_post(nullptr, p, 0).bytes;
   RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
@@ -1532,6 +1980,7 @@ int rh_postprocess(const float* classifications, const float* regressions, const
              "anchors, regressions and out_boxes must be 16-byte aligned");
   RH_REQUIRE((stages & ~RH_POST_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
   const NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
+  if (int e = check_plan(p)) return e;
   const int total_rows = (int)((long long)batch * n);
   const int num_tiles = (total_rows + kTileRows - 1) / kTileRows;
   const size_t need = carve_post(nullptr, p, num_tiles).bytes;
@@ -1659,6 +2108,7 @@ int rh_postprocess_levels(const float* const* cls_levels, const float* const* re
   const long long num_tiles = (long long)batch * tiles_per_image;
   RH_REQUIRE(num_tiles < (1ll << 31), RH_ESHAPE, "too many tile lists");
   const NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
+  if (int e = check_plan(p)) return e;
   const size_t need = carve_post(nullptr, p, num_tiles).bytes;
   RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);

@@ -100,32 +100,6 @@ struct CodeLayout {
   int hw[kMaxLevels];
 };
 
-// Minimum / maximum over the wave, as a wave-uniform value: inclusive scan by DPP row shifts
-// (1, 2, 4, 8 lanes inside each row of 16), then the row broadcasts 15 -> rows 1, 3 and
-// 31 -> rows 2, 3; lane 63 ends up with the result.  Lanes without a source keep `ident`.
-template <bool kMax>
-__device__ __forceinline__ float wave_extreme(float v) {
-  const int ident = __float_as_int(kMax ? -__builtin_inff() : __builtin_inff());
-#define RH_DPP_STEP(ctrl, rows)                                                               \
-  {                                                                                           \
-    const float t = __int_as_float(                                                           \
-        __builtin_amdgcn_update_dpp(ident, __float_as_int(v), ctrl, rows, 0xf, false));       \
-    v = kMax ? vmax(v, t) : vmin(v, t);                                                       \
-  }
-  RH_DPP_STEP(0x111, 0xf)
-  RH_DPP_STEP(0x112, 0xf)
-  RH_DPP_STEP(0x114, 0xf)
-  RH_DPP_STEP(0x118, 0xf)
-  RH_DPP_STEP(0x142, 0xa)
-  RH_DPP_STEP(0x143, 0xc)
-#undef RH_DPP_STEP
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-__device__ __forceinline__ float lane_value(const float v, const int src_lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
-}
-
 struct AnnRow {
   float x1, y1, x2, y2, lab;
 };
