@@ -22,7 +22,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // Build-time diagnostic (-DRH_TIMELINE): thread 0 of every block stores wall-clock stamps
 // (100 MHz) at the marked places; rh_tl_read() copies them out.  Not part of the shipped library.
 #ifdef RH_TIMELINE
-constexpr int kTlBlocks = 8192, kTlSlots = 8;
+constexpr int kTlBlocks = 8192, kTlSlots = 12;
 __device__ long long rh_tl[3][kTlBlocks][kTlSlots];
 #define RH_TL(kernel, slot)                                                                     \
   do {                                                                                          \
@@ -1197,6 +1197,7 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
 
   int taken = 0;                                    // units seen so far
   RH_TL(1, 2);
+  RH_TL_VALUE(1, 8, (long long)__builtin_amdgcn_s_memtime());
   RH_TL_DO(int tl_tiles = 0, tl_surv = 0, tl_nset = 0; long long tl_a = 0, tl_t = 0, tl_set = 0;)
   for (int b0 = A; b0 < C; b0 += 64) {
     // ---- cluster test, 64 clusters per ballot (the first 64 summaries were requested up front)
@@ -1270,6 +1271,7 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
     }
   }
   RH_TL(1, 3);
+  RH_TL_VALUE(1, 9, (long long)__builtin_amdgcn_s_memtime());
   RH_TL_VALUE(1, 4, tl_tiles);
   RH_TL_VALUE(1, 5, tl_surv);
   RH_TL_VALUE(1, 6, tl_a);
@@ -1359,7 +1361,8 @@ constexpr int kResolveWaves = 16;
 constexpr int kResolveThreads = 64 * kResolveWaves;
 
 __host__ __device__ inline size_t resolve_lds_bytes(int wstride) {
-  return (size_t)wstride * 2 * sizeof(u64) + ((size_t)wstride + 1) * sizeof(int);
+  // lo and hi bitmaps, kept-before-chunk counts, three "still open" flags
+  return (size_t)wstride * 2 * sizeof(u64) + ((size_t)wstride + 1 + 3) * sizeof(int);
 }
 
 // A box's predecessor words as the cached form holds them.
@@ -1420,10 +1423,12 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
   extern __shared__ __attribute__((aligned(16))) u64 s_lo[];      // [wstride] surely kept
   u64* s_hi = s_lo + wstride;                                     // [wstride] possibly kept
   int* s_total = reinterpret_cast<int*>(s_hi + wstride);          // [wstride + 1] kept before chunk c
+  int* s_open = s_total + wstride + 1;                            // [3] a chunk still has open boxes
   const int j = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   RH_TL(2, 0);
+  RH_TL_VALUE(2, 8, (long long)__builtin_amdgcn_s_memtime());
   const int K = keff[j];
   const int W = (K + 63) >> 6;
   const u64* kj = keys + (size_t)j * key_stride;
@@ -1438,6 +1443,7 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
   constexpr int kCached = kSlots > 0 ? kSlots : 1;
   const int nslots = kSlots > 0 ? kSlots : (W + kResolveWaves - 1) / kResolveWaves;
 
+  if (threadIdx.x == 0) s_open[0] = 0;
   // ---- start: lo = nothing, hi = every box
   for (int s = 0; s < nslots; ++s) {
     const int c = s * kResolveWaves + wave;
@@ -1451,34 +1457,28 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
   // together, then the first two predecessor words of every box, unconditionally (indices
   // clamped into the mask; a word that is not there is loaded from word 0 and discarded)
   BoxPreds pr[kCached];
-  u64 okey[kCached];        // what the outputs need, requested now and used after the rounds
-  float4 obox[kCached];
-  int olab[kCached];
   if (kSlots > 0) {
     u64 bits[kCached];
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
-      const int c = s * kResolveWaves + wave;
-      const int row = min(c * 64 + lane, max(K - 1, 0));
+      // (rows clamped by the arrays' size, not by K: these loads go out beside the load of K)
+      const int row = min((s * kResolveWaves + wave) * 64 + lane, box_stride - 1);
       bits[s] = nj[(size_t)row * nzw];
-      okey[s] = kj[row];
-      obox[s] = bj[row];
-      olab[s] = lj ? lj[row] : 0;
     }
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
       const int c = s * kResolveWaves + wave;
-      const int row = min(c * 64 + lane, max(K - 1, 0));
+      const int row = min(c * 64 + lane, box_stride - 1);
       const bool live = c < W && c * 64 + lane < K;
       u64 b = live ? bits[s] : 0ull;
       // a box without predecessor words is kept: the first round is done here
       const u64 free_now = __ballot(live && b == 0ull);
       if (c < W && lane == 0) s_lo[c] = free_now;
       const bool has0 = b != 0ull;
-      pr[s].i0 = has0 ? __builtin_ctzll(b) : 0;
+      pr[s].i0 = has0 ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
       b &= b - 1ull;
       const bool has1 = b != 0ull;
-      pr[s].i1 = has1 ? __builtin_ctzll(b) : 0;
+      pr[s].i1 = has1 ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
       b &= b - 1ull;
       pr[s].more = b != 0ull;
       const u64 x = mj[(size_t)pr[s].i0 * box_stride + row];
@@ -1501,7 +1501,9 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       if (kSlots > 0) {
         d = (p.w0 & s_lo[p.i0]) | (p.w1 & s_lo[p.i1]);
         m = (p.w0 & s_hi[p.i0]) | (p.w1 & s_hi[p.i1]);
-        if (p.more && d == 0ull)
+        // the further words only matter once the cached ones neither drop the box nor hold a
+        // predecessor that is still open (while one is, the box stays open whatever they say)
+        if (p.more && d == 0ull && m == 0ull)
           scan_words(s_lo, s_hi, nj + (size_t)row * nzw, nzw, mj, box_stride, row, 2, d, m);
       } else {
         scan_words(s_lo, s_hi, nj + (size_t)row * nzw, nzw, mj, box_stride, row, 0, d, m);
@@ -1539,11 +1541,20 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
     } else {
       for (int c = wave; c < W; c += kResolveWaves) open_any |= round_of(c, pr[0]);
     }
-    if (!__syncthreads_or(open_any)) break;
+    // "does any chunk still have an open box?" through a flag in LDS, one barrier per round
+    // (the library's workgroup-wide OR costs well over a microsecond for 16 waves).  Three flags
+    // in rotation: the one cleared here was last read two barriers ago.
+    if (threadIdx.x == 0) s_open[(round + 1) % 3] = 0;
+    if (open_any && lane == 0) s_open[round % 3] = 1;
+    __syncthreads();
+    const int again = s_open[round % 3];
+    RH_TL_DO(if (round == 0) RH_TL(2, 4); if (round == 1) RH_TL(2, 6); if (round == 2) RH_TL(2, 7);)
+    if (!again) break;
   }
 
   // ---- kept boxes before each chunk (wave 0), then the outputs
   RH_TL(2, 2);
+  RH_TL_VALUE(2, 9, (long long)__builtin_amdgcn_s_memtime());
   RH_TL_VALUE(2, 5, tl_rounds);
   if (wave == 0) {
     int run = 0;
@@ -1578,17 +1589,9 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       }
     }
   };
-  if (kSlots > 0) {
-#pragma unroll
-    for (int s = 0; s < kCached; ++s) {
-      const int c = s * kResolveWaves + wave;
-      if (c < W) emit(c, okey[s], obox[s], olab[s]);
-    }
-  } else {
-    for (int c = wave; c < W; c += kResolveWaves) {
-      const int row = min(c * 64 + lane, K - 1);
-      emit(c, kj[row], bj[row], lj ? lj[row] : 0);
-    }
+  for (int c = wave; c < W; c += kResolveWaves) {
+    const int row = min(c * 64 + lane, K - 1);
+    emit(c, kj[row], bj[row], lj ? lj[row] : 0);
   }
   RH_TL(2, 3);
 }

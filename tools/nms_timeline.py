@@ -22,8 +22,9 @@ from retinahead import functional as F  # noqa: E402
 
 KERNELS = {0: ("sort_rank", ["start", "count pass", "list in LDS", "ranks counted", "end"]),
            1: ("nms_pairs", ["start", "counters read", "own cluster loaded", "end"]),
-           2: ("nms_resolve", ["start", "words loaded", "rounds done", "end"])}
-BLOCKS, SLOTS = 8192, 8
+           2: ("nms_resolve", ["start", "words loaded", "rounds done", "end", "round 1 done", None,
+                               "round 2 done", "round 3 done"])}
+BLOCKS, SLOTS = 8192, 12
 
 
 def main():
@@ -49,12 +50,19 @@ def main():
         t0 = t[:, 0].min()
         print(f"{name}: {live.sum()} workgroups, starts spread over {(t[:, 0].max() - t0) / 100:.2f} us")
         for m, label in enumerate(marks):
+            if label is None:
+                continue
             v = t[:, m]
             v = v[v > 0]
             if v.size:
                 rel = (v - t0) / 100.0
                 print(f"   {label:22s} median {np.median(rel):7.2f}  p90 {np.percentile(rel, 90):7.2f}  max {rel.max():7.2f} us"
                       f"   ({v.size} workgroups)")
+        if k in (1, 2):
+            a, b = (2, 3) if k == 1 else (0, 2)
+            ok = (t[:, 9] > 0) & (t[:, b] > t[:, a])
+            ghz = (t[ok, 9] - t[ok, 8]) / ((t[ok, b] - t[ok, a]) * 10.0)
+            print(f"   shader clock while it ran: median {np.median(ghz):.2f} GHz (min {ghz.min():.2f}, max {ghz.max():.2f})")
         if k == 1:
             done = t[t[:, 3] > 0]
             dur = (done[:, 3] - done[:, 2]) / 100.0
