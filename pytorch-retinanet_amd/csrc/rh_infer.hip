@@ -1160,31 +1160,35 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
 
   // lanes of `mine` that may overlap box b (record info) by more than thresh (almost always
   // none).  The box is wave-uniform and sits in scalar registers.
-  auto possible = [&](const float4 b, const int4 info) -> u64 {
+  auto possible = [&](const float4 b, const int4 info, float& inter, float& sum) -> u64 {
     const float w = vmin_s(b.z, mine.z) - vmax_s(b.x, mine.x);
     const float h = vmin_s(b.w, mine.w) - vmax_s(b.y, mine.y);
-    float inter = vmax0(w) * h;
+    inter = vmax0(w) * h;
     if (kPerClass) inter = info.y == me.lab ? inter : -1.0f;
-    // inter > thresh * ((area + AREA) - inter), solved for inter and loosened by 2^-19 (this is
-    // only the filter: whatever passes is decided exactly below, and a pair that the exact test
-    // accepts passes here with room to spare)
-    return __ballot(inter > (area + __int_as_float(info.z)) * k_filter);
+    sum = area + __int_as_float(info.z);
+    // inter > thresh * (sum - inter), solved for inter and loosened by 2^-19 (this is only the
+    // filter: whatever passes is decided exactly below, and a pair that the exact test accepts
+    // passes here with room to spare)
+    return __ballot(inter > sum * k_filter);
   };
-  // decide and record the pairs (lane, box) of `hit`; src = the box's lane in cluster B
-  auto settle = [&](const float4 b, const int4 info, const int erank, const int src, const bool same,
-                    u64 hit) {
+  // decide and record the pairs (lane, box) of `hit`; src = the box's lane in cluster B;
+  // inter, sum: the lane's values from possible()
+  auto settle = [&](const float4 b, const int erank, const int src, const bool same, u64 hit,
+                    const float inter, const float sum) {
     // inside one cluster each unordered pair once: only the lanes above the box's own
     hit &= same ? lanes_ok & ~((2ull << src) - 1ull) : lanes_ok;
     if (hit == 0ull) return;
     if ((hit >> lane) & 1ull) {
-      const float w = fmaxf(0.0f, fminf(mine.z, b.z) - fmaxf(mine.x, b.x));
-      const float h = fmaxf(0.0f, fminf(mine.w, b.w) - fmaxf(mine.y, b.y));
-      const float inter = w * h;
-      const float denom = (area + __int_as_float(info.z)) - inter;
-      // clear of the 2^-20 band around the threshold the product test is exact enough;
-      // inside it the float32 division of torchvision's arithmetic decides
-      bool sure = inter > fmaxf(denom, 0.0f) * c_hi;
-      if (__ballot(!sure) != 0ull) sure = sure || nms_hit_exact(inter, denom, thresh);
+      // Clear of the 2^-20 band around the threshold the product test decides (a positive inter
+      // means positive overlap in x and y, where it equals the clamped product the division
+      // form uses); inside the band the float32 division of torchvision's arithmetic decides.
+      bool sure = inter > fmaxf(sum - inter, 0.0f) * c_hi;
+      if (__ballot(!sure) != 0ull) {
+        const float w = fmaxf(0.0f, fminf(mine.z, b.z) - fmaxf(mine.x, b.x));
+        const float h = fmaxf(0.0f, fminf(mine.w, b.w) - fmaxf(mine.y, b.y));
+        const float exact_inter = w * h;
+        sure = sure || nms_hit_exact(exact_inter, sum - exact_inter, thresh);
+      }
       if (sure) {
         const int brank = __builtin_amdgcn_readlane(erank, src);
         const int first = min(me.rank, brank), later = max(me.rank, brank);
@@ -1258,12 +1262,13 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
                               __builtin_amdgcn_readlane(__float_as_int(e.area), src[u]), 0);
         }
         u64 h[4];
+        float inter[4], sum[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) h[u] = possible(box[u], info[u]);
+        for (int u = 0; u < 4; ++u) h[u] = possible(box[u], info[u], inter[u], sum[u]);
         if ((h[0] | h[1] | h[2] | h[3]) != 0ull) {
           RH_TL_DO(const long long tl_s = wall_clock64(); ++tl_nset;)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) settle(box[u], info[u], e.rank, src[u], B == A, h[u]);
+          for (int u = 0; u < 4; ++u) settle(box[u], e.rank, src[u], B == A, h[u], inter[u], sum[u]);
           RH_TL_DO(tl_set += wall_clock64() - tl_s;)
         }
       }
@@ -1457,6 +1462,9 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
   // together, then the first two predecessor words of every box, unconditionally (indices
   // clamped into the mask; a word that is not there is loaded from word 0 and discarded)
   BoxPreds pr[kCached];
+  u64 okey[kCached];        // what the outputs need, requested now and used after the rounds
+  float4 obox[kCached];
+  int olab[kCached];
   if (kSlots > 0) {
     u64 bits[kCached];
 #pragma unroll
@@ -1464,6 +1472,9 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       // (rows clamped by the arrays' size, not by K: these loads go out beside the load of K)
       const int row = min((s * kResolveWaves + wave) * 64 + lane, box_stride - 1);
       bits[s] = nj[(size_t)row * nzw];
+      okey[s] = kj[row];
+      obox[s] = bj[row];
+      olab[s] = lj ? lj[row] : 0;
     }
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
@@ -1589,9 +1600,17 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       }
     }
   };
-  for (int c = wave; c < W; c += kResolveWaves) {
-    const int row = min(c * 64 + lane, K - 1);
-    emit(c, kj[row], bj[row], lj ? lj[row] : 0);
+  if (kSlots > 0) {
+#pragma unroll
+    for (int s = 0; s < kCached; ++s) {
+      const int c = s * kResolveWaves + wave;
+      if (c < W) emit(c, okey[s], obox[s], olab[s]);
+    }
+  } else {
+    for (int c = wave; c < W; c += kResolveWaves) {
+      const int row = min(c * 64 + lane, K - 1);
+      emit(c, kj[row], bj[row], lj ? lj[row] : 0);
+    }
   }
   RH_TL(2, 3);
 }
