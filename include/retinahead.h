@@ -167,7 +167,14 @@ typedef struct rh_focal_params {
 
 void rh_focal_params_default(rh_focal_params* p);
 
-/* Stages of the fused call, for profiling; RH_STAGE_ALL runs the whole path. */
+/* Stages of the fused call; RH_STAGE_ALL runs the whole path.  The stages of one step share its
+ * workspace and may be issued by separate calls.  RH_STAGE_ASSIGN alone reads only anchors and
+ * annotations (the prediction, gradient and loss pointers may be NULL; status and, under
+ * RH_NORM_GLOBAL, num_pos are written), so a trainer that has the next batch's annotations early
+ * can run it on a second stream, into a second workspace, while the current step's
+ * RH_STAGE_STREAM is still running: the stream stage leaves the vector ALUs mostly idle.  The
+ * caller orders the streams (the later stages of a step after its assignment stage; a
+ * workspace's next assignment after the stages that still read it). */
 enum rh_focal_stage {
   RH_STAGE_ASSIGN = 1,   /* GT compaction + IoU assignment + num_pos            */
   RH_STAGE_STREAM = 2,   /* N x C focal stream + smooth-L1, losses and gradients */
@@ -182,6 +189,32 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                           float* d_classifications, float* d_regressions, float* losses,
                           float* per_image, int32_t* num_pos, int32_t* status, void* workspace,
                           size_t workspace_bytes, int32_t stages, rh_stream_t stream);
+
+/* The same call, which also runs the RH_STAGE_ASSIGN stage of the NEXT step (losses.py:57-79 for
+ * the next batch's annotations: same anchors, B, N and class count; its own row count m) inside
+ * this step's stream launch, where it costs about a fifth of a launch of its own.  The next step
+ * is then called with stages = RH_STAGE_STREAM | RH_STAGE_FINALIZE, next->workspace as its
+ * workspace and next->status / next->num_pos as the outputs the assignment wrote (num_pos only
+ * under RH_NORM_GLOBAL; either may be NULL).  `stages` must include RH_STAGE_STREAM; next == NULL
+ * is rh_focal_loss_fwd_bwd.  The reference has no counterpart: its assignment is part of the
+ * loss's forward, losses.py:57-79, and runs when the predictions arrive. */
+typedef struct rh_assign_ahead {
+  const float* annotations;  /* device [B,m,5], the next step's */
+  int32_t m;
+  void* workspace;           /* the next step's workspace, not this step's */
+  size_t workspace_bytes;    /* >= rh_focal_loss_workspace_bytes(batch, n, num_classes, m) */
+  int32_t* status;           /* device i32 [B] or NULL */
+  int32_t* num_pos;          /* device i32 [B] or NULL */
+} rh_assign_ahead;
+
+int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regressions,
+                                const float* anchors, const float* annotations, int32_t batch,
+                                int64_t n, int32_t num_classes, int32_t m,
+                                const rh_focal_params* params, float* d_classifications,
+                                float* d_regressions, float* losses, float* per_image,
+                                int32_t* num_pos, int32_t* status, void* workspace,
+                                size_t workspace_bytes, int32_t stages, const rh_assign_ahead* next,
+                                rh_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * The same fused loss, reading the heads' outputs where they lie: per pyramid level l a

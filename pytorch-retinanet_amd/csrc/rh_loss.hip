@@ -122,27 +122,51 @@ __device__ long long rh_dbg[8 * 65536];
 #else
 #define RH_MARK(slot)
 #endif
-// (at most six waves per SIMD: 11.4 against 11.7 us with eight)
+// Everything the assignment of one batch reads and writes.
+struct AssignArgs {
+  const float4* anchors;
+  const float* ann;
+  GtRec* gt;
+  int* gt_count;
+  int* status;
+  int* code;
+  unsigned char* state;
+  int* argmax;
+  int* label;
+  float* iou_max;
+  int* blk_pos;
+  int N, M, C;
+  float neg_thresh, pos_thresh;
+  CodeLayout lay;
+};
+
+// The work of block bx (of nblk) of image j.  Blocks are best started from the last one down:
+// the blocks of the coarse pyramid levels, whose large anchors meet most GT boxes, are the long
+// ones.
 template <bool kSplit>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))) void assign_kernel(
-    const float4* __restrict__ anchors, const float* __restrict__ ann, GtRec* __restrict__ gt,
-    int* __restrict__ gt_count, int* __restrict__ status, int* __restrict__ code,
-    unsigned char* __restrict__ state, int* __restrict__ argmax, int* __restrict__ label,
-    float* __restrict__ iou_max, int* __restrict__ blk_pos, int N, int M, int C,
-    float neg_thresh, float pos_thresh, CodeLayout lay) {
+__device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, const int bx,
+                                             const int nblk) {
   __shared__ int s_cnt[kThreads / 64];
   constexpr int kShare = kSplit ? kSplitAnchors : 1;
   __shared__ float s_best[kThreads / 64][kShare];
   __shared__ int s_bidx[kThreads / 64][kShare];
   __shared__ int s_blab[kThreads / 64][kShare];
+  const float4* __restrict__ anchors = aa.anchors;
+  const float* __restrict__ ann = aa.ann;
+  GtRec* __restrict__ gt = aa.gt;
+  int* __restrict__ gt_count = aa.gt_count;
+  int* __restrict__ status = aa.status;
+  int* __restrict__ code = aa.code;
+  unsigned char* __restrict__ state = aa.state;
+  int* __restrict__ argmax = aa.argmax;
+  int* __restrict__ label = aa.label;
+  float* __restrict__ iou_max = aa.iou_max;
+  int* __restrict__ blk_pos = aa.blk_pos;
+  const int N = aa.N, M = aa.M, C = aa.C;
+  const float neg_thresh = aa.neg_thresh, pos_thresh = aa.pos_thresh;
+  const CodeLayout& lay = aa.lay;
   RH_MARK(0);
 
-  // Grid (image, block), blocks taken from the last one down: the blocks of the coarse pyramid
-  // levels, whose large anchors meet most GT boxes, are the long ones and start first, for
-  // every image at once.  (A one-dimensional grid that also puts the B workgroups reading the
-  // same 512 anchors on one XCD, to share its L2, was measured: 12.0 against 11.5 us.)
-  const int j = blockIdx.x;
-  const int bx = (int)gridDim.y - 1 - (int)blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // anchors of thread t: base + k * stride.  Split form: every wave holds the same anchors.
   constexpr int kStride = kSplit ? 64 : kThreads;
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
   }
   npos = wave_sum(npos);
   if (kSplit) {             // only wave 0 is left, and it holds the block's anchors
-    if (lane == 0) blk_pos[(size_t)j * gridDim.y + bx] = npos;
+    if (lane == 0) blk_pos[(size_t)j * nblk + bx] = npos;
   } else {
     if (lane == 0) s_cnt[wave] = npos;
     __syncthreads();
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
       int t = 0;
 #pragma unroll
       for (int w = 0; w < kThreads / 64; ++w) t += s_cnt[w];
-      blk_pos[(size_t)j * gridDim.y + bx] = t;
+      blk_pos[(size_t)j * nblk + bx] = t;
     }
   }
   if (publisher) {          // this wave has seen every row of the image
@@ -350,6 +374,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))
     }
   }
   RH_MARK(3);
+}
+
+// Grid (image, block), blocks taken from the last one down, for every image at once.  (A
+// one-dimensional grid that also puts the B workgroups reading the same 512 anchors on one XCD,
+// to share its L2, was measured: 12.0 against 11.5 us.)
+// (at most six waves per SIMD: 11.4 against 11.7 us with eight)
+template <bool kSplit>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 6))) void assign_kernel(
+    const AssignArgs aa) {
+  assign_block<kSplit>(aa, blockIdx.x, (int)gridDim.y - 1 - (int)blockIdx.y, gridDim.y);
 }
 #ifdef RH_TIMELINE
 extern "C" int rh_dbg_read(long long* out, size_t count) {
@@ -546,14 +580,42 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // head-layout kernel, gains under 1 % here and costs a spill: not done.)
 // Five waves per SIMD (at most 96 vector registers; the compiler's own choice was 99, i.e. four
 // waves): measured 120.0 against 121.5 us.  Six waves need spills and take 156 us.
-template <int U, bool kLogits>
+//
+// kAhead: the launch also carries the IoU assignment of the NEXT step (its annotations are known
+// before its predictions are).  Its workgroups are the last of the grid, image-major from the
+// long blocks down like the stand-alone kernel's: they take the workgroup slots that the stream
+// leaves empty as its last tiles drain, and end about 6 us after it, against 11 us plus a kernel
+// boundary for a launch of their own.  (Measured at B=16, N=69354, C=80, step time with the
+// assignment placed: in its own launch 142.5 us; at the front of the grid, where its 2176
+// workgroups fill every slot of the chip and the stream starts only as they finish, 140.6 us;
+// one in every six workgroups over the first 70 % of the grid 146.5 us -- the stream is bound by
+// the loads its resident workgroups keep in flight, so every slot lent out costs its share; at
+// the end of the grid 137.2 us.)
+struct AheadArgs {
+  AssignArgs aa;
+  int first;    // first assignment workgroup = number of stream workgroups
+  int batch;
+  int nblk;
+};
+
+template <int U, bool kLogits, bool kAhead>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
     float* __restrict__ partials, int N, int C, int M, int total_rows, int num_tiles,
     unsigned magic_c, FocalConst fc, float gcls, float greg, float divisor,
-    const float* __restrict__ pos_total, int parts, int part_vecs) {
+    const float* __restrict__ pos_total, int parts, int part_vecs, const AheadArgs ahead) {
+  int unit_stride = gridDim.x;
+  if (kAhead) {
+    const int at = (int)blockIdx.x - ahead.first;
+    if (at >= 0) {
+      const int b = at / ahead.batch;
+      assign_block<false>(ahead.aa, at - b * ahead.batch, ahead.nblk - 1 - b, ahead.nblk);
+      return;
+    }
+    unit_stride = ahead.first;
+  }
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
   __shared__ int s_np[kThreads / 64][2];
@@ -566,7 +628,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
   // workgroup streams about as much as it does at C = 80 -- short-lived workgroups whose loads
   // all go out at once, and enough of them to fill the chip evenly.  Part 0 also does the
   // tile's regression rows.
-  for (int unit = blockIdx.x; unit < num_tiles * parts; unit += gridDim.x) {
+  for (int unit = blockIdx.x; unit < num_tiles * parts; unit += unit_stride) {
     const int tile = parts == 1 ? unit : unit / parts;
     const int part = unit - tile * parts;
     const int row0 = tile * kTileRows;
@@ -745,9 +807,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     __syncthreads();
     if (tid == 0) {
       const float4 a = s_red[0], b = s_red[1], c = s_red[2], d = s_red[3];
+      // record: (classification, regression) of the tile's first image, then of its second
       reinterpret_cast<float4*>(partials)[unit] =
-          make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y),
-                      (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+          make_float4((a.x + b.x) + (c.x + d.x), (a.z + b.z) + (c.z + d.z),
+                      (a.y + b.y) + (c.y + d.y), (a.w + b.w) + (c.w + d.w));
     }
   }
 }
@@ -1031,6 +1094,7 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
 // tile_mode float4 per tile; 0: the row / level kernels' [B][blocks][2].
 // ---------------------------------------------------------------------------
 constexpr int kFinalThreads = 1024;
+constexpr int kFinalBatch = 9;
 
 __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     const float* __restrict__ partials, const int* __restrict__ blk_pos, int nblk,
@@ -1048,6 +1112,13 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
     int pos = 0;
     if (j < B) {
       double c = 0.0, r = 0.0;
+      // the small loads go out with the first batch of records, not after the last
+      int npv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) npv[k] = blk_pos[(size_t)j * nblk + min(lane + k * 64, nblk - 1)];
+      const int gtc = gt_count[j];
+      const float total = pos_total ? *pos_total : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
       if (tile_mode) {
         const long long first = (long long)j * N, last = first + N - 1;
         const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
@@ -1055,12 +1126,26 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
         // image is the tile's second one
         const bool shared_first = (first % kTileRows) != 0;
         const int u_shared = (t_lo + 1) * tile_mode;      // records below it belong to tile t_lo
-#pragma unroll 8
-        for (int u = t_lo * tile_mode + lane; u < (t_hi + 1) * tile_mode; u += 64) {
-          const float4 q = reinterpret_cast<const float4*>(partials)[u];
-          const bool second = shared_first && u < u_shared;
-          c += second ? q.y : q.x;
-          r += second ? q.w : q.z;
+        // (kFinalBatch loads in flight per lane, only the half of each record that belongs to
+        // this image, and the small loads above issued with them: 6.0 -> 5.4 us at 1084 tiles
+        // per image.  Twice the batch changes nothing: what remains is the launch, one trip to
+        // memory, the barriers and the final stores.)
+        const int u_end = (t_hi + 1) * tile_mode;
+#pragma nounroll
+        for (int u0 = t_lo * tile_mode + lane; u0 < u_end; u0 += 64 * kFinalBatch) {
+          float2 q[kFinalBatch];      // the half of each record that is this image's
+#pragma unroll
+          for (int k = 0; k < kFinalBatch; ++k) {
+            const int u = min(u0 + k * 64, u_end - 1);
+            q[k] = reinterpret_cast<const float2*>(partials)[2 * u + (shared_first && u < u_shared)];
+          }
+#pragma unroll
+          for (int k = 0; k < kFinalBatch; ++k) {
+            if (u0 + k * 64 < u_end) {
+              c += q[k].x;
+              r += q[k].y;
+            }
+          }
         }
       } else {
         // (unrolled: the loads of eight rounds go out together instead of one latency each)
@@ -1073,15 +1158,17 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
         }
       }
       int np = 0;
-      for (int i = lane; i < nblk; i += 64) np += blk_pos[(size_t)j * nblk + i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) np += lane + k * 64 < nblk ? npv[k] : 0;
+      for (int i = lane + 256; i < nblk; i += 64) np += blk_pos[(size_t)j * nblk + i];
+      const bool empty = gtc == 0;
       c = wave_sum(c);
       r = wave_sum(r);
       np = wave_sum(np);
       pos = np;
-      const bool empty = gt_count[j] == 0;
       // batch-wide normaliser: every image is divided by the one total (an image's share of
       // the batch loss); otherwise by its own count, losses.py:94 and :134
-      const float npf = pos_total ? *pos_total : (float)np;
+      const float npf = pos_total ? total : (float)np;
       cl = empty ? 0.f : (float)c / fmaxf(npf, 1.f);
       rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * npf);
       if (lane == 0) {
@@ -1199,6 +1286,31 @@ static int check_assign_shapes(int batch, long long n, int m, int c) {
   return RH_OK;
 }
 
+static AssignArgs assign_args(const float* anchors, const float* annotations, long long n, int m,
+                              int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
+                              unsigned char* state, int* argmax, int* label, float* iou_max,
+                              int* status, const CodeLayout& lay) {
+  AssignArgs aa;
+  aa.anchors = reinterpret_cast<const float4*>(anchors);
+  aa.ann = annotations;
+  aa.gt = w.gt;
+  aa.gt_count = w.gt_count;
+  aa.status = status;
+  aa.code = code;
+  aa.state = state;
+  aa.argmax = argmax;
+  aa.label = label;
+  aa.iou_max = iou_max;
+  aa.blk_pos = w.blk_pos;
+  aa.N = (int)n;
+  aa.M = m;
+  aa.C = c;
+  aa.neg_thresh = neg_t;
+  aa.pos_thresh = pos_t;
+  aa.lay = lay;
+  return aa;
+}
+
 static int launch_assign(const float* anchors, const float* annotations, int batch, long long n,
                          int m, int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                          unsigned char* state, int* argmax, int* label, float* iou_max, int* status,
@@ -1206,8 +1318,8 @@ static int launch_assign(const float* anchors, const float* annotations, int bat
   RH_REQUIRE(w.nblk <= 65535, RH_ESHAPE, "n=%lld with m=%d: more than 65535 assignment blocks per image", n, m);
   dim3 grid((unsigned)batch, (unsigned)w.nblk);
   hipLaunchKernelGGL(assign_split(m) ? assign_kernel<true> : assign_kernel<false>, grid, dim3(kThreads), 0, s,
-                     reinterpret_cast<const float4*>(anchors), annotations, w.gt, w.gt_count, status,
-                     code, state, argmax, label, iou_max, w.blk_pos, (int)n, m, c, neg_t, pos_t, lay);
+                     assign_args(anchors, annotations, n, m, c, neg_t, pos_t, w, code, state, argmax,
+                                 label, iou_max, status, lay));
   RH_CHECK_LAUNCH("assign_kernel");
   return RH_OK;
 }
@@ -1368,16 +1480,50 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                           float* d_classifications, float* d_regressions, float* losses,
                           float* per_image, int32_t* num_pos, int32_t* status, void* workspace,
                           size_t workspace_bytes, int32_t stages, rh_stream_t stream) {
+  return rh_focal_loss_fwd_bwd_ahead(classifications, regressions, anchors, annotations, batch, n,
+                                     num_classes, m, params, d_classifications, d_regressions,
+                                     losses, per_image, num_pos, status, workspace, workspace_bytes,
+                                     stages, nullptr, stream);
+}
+
+int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regressions,
+                                const float* anchors, const float* annotations, int32_t batch,
+                                int64_t n, int32_t num_classes, int32_t m,
+                                const rh_focal_params* params, float* d_classifications,
+                                float* d_regressions, float* losses, float* per_image,
+                                int32_t* num_pos, int32_t* status, void* workspace,
+                                size_t workspace_bytes, int32_t stages, const rh_assign_ahead* next,
+                                rh_stream_t stream) {
   if (int e = check_assign_shapes(batch, n, m, num_classes)) return e;
-  RH_REQUIRE(classifications && regressions && anchors && (annotations || m == 0) &&
-                 d_classifications && d_regressions && losses && params,
-             RH_EINVAL, "null pointer");
+  LossWorkspace wn{};
+  if (next) {
+    RH_REQUIRE(stages & RH_STAGE_STREAM, RH_EINVAL,
+               "the next step's assignment rides on the stream stage: stages=%d has none", stages);
+    if (int e = check_assign_shapes(batch, n, next->m, num_classes)) return e;
+    RH_REQUIRE(next->annotations || next->m == 0, RH_EINVAL, "null pointer");
+    const size_t need_next = rh_focal_loss_workspace_bytes(batch, n, num_classes, next->m);
+    RH_REQUIRE(next->workspace && next->workspace_bytes >= need_next, RH_EWORKSPACE,
+               "next step's workspace too small: need %zu bytes, got %zu", need_next,
+               next->workspace_bytes);
+    RH_REQUIRE(aligned16(next->workspace), RH_EALIGN, "workspace must be 16-byte aligned");
+    RH_REQUIRE(next->workspace != workspace, RH_EINVAL,
+               "the next step needs a workspace of its own: this step's is still being read");
+    wn = carve_loss(next->workspace, batch, n, num_classes, next->m);
+  }
+  RH_REQUIRE((stages & ~RH_STAGE_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
+  // The assignment stage reads the anchors and the annotations only, so it can be run ahead of
+  // the step that owns the predictions (into that step's workspace); the other stages need the
+  // prediction and gradient tensors (the final reduction for their alignment, which selects the
+  // kernel whose partial sums it reads).
+  RH_REQUIRE(anchors && (annotations || m == 0) && params, RH_EINVAL, "null pointer");
+  if (stages & (RH_STAGE_STREAM | RH_STAGE_FINALIZE))
+    RH_REQUIRE(classifications && regressions && d_classifications && d_regressions && losses,
+               RH_EINVAL, "null pointer");
   RH_REQUIRE(aligned16(anchors), RH_EALIGN, "anchors must be 16-byte aligned");
   const size_t need = rh_focal_loss_workspace_bytes(batch, n, num_classes, m);
   RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
-  RH_REQUIRE((stages & ~RH_STAGE_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
 
   hipStream_t s = (hipStream_t)stream;
   const LossWorkspace w = carve_loss(workspace, batch, n, num_classes, m);
@@ -1398,6 +1544,7 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
     if (params->normalizer == RH_NORM_GLOBAL)
       if (int e = launch_count(w, batch, num_pos, s)) return e;
   }
+  bool next_assigned = false;
   if (stages & RH_STAGE_STREAM) {
     if (tile) {
       // float4 slots per thread and part: pick the unroll that wastes the fewest
@@ -1410,15 +1557,33 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
       // One tile per workgroup: the hardware dispatcher balances the 17k+ tiles better than a
       // grid-stride loop did (measured 125 us against 142 us at B=16, N=69354, C=80), and
       // non-temporal loads and stores (the data is touched once) were worth another 8 %.
+      // The next step's assignment joins this launch in its plain form (short annotation lists);
+      // otherwise it follows as a launch of its own below.
+      AheadArgs ahead{};
+      int ahead_blocks = 0;
+      const bool ride = next && !assign_split(next->m) &&
+                        (long long)num_tiles * parts + (long long)batch * wn.nblk < (1ll << 31);
+      if (ride) {
+        ahead.aa = assign_args(anchors, next->annotations, n, next->m, num_classes,
+                               params->neg_thresh, params->pos_thresh, wn, wn.code, nullptr, nullptr,
+                               nullptr, nullptr, next->status, CodeLayout{});
+        ahead.batch = batch;
+        ahead.nblk = wn.nblk;
+        ahead.first = num_tiles * parts;
+        ahead_blocks = batch * wn.nblk;
+        next_assigned = true;
+      }
       auto kern = params->from_logits
-                      ? (u5 ? focal_stream_kernel<5, true> : focal_stream_kernel<4, true>)
-                      : (u5 ? focal_stream_kernel<5, false> : focal_stream_kernel<4, false>);
-      hipLaunchKernelGGL(kern, dim3(num_tiles * parts), dim3(kThreads), 0, s, classifications,
-                         d_classifications, regressions, d_regressions,
+                      ? (u5 ? (ride ? focal_stream_kernel<5, true, true> : focal_stream_kernel<5, true, false>)
+                            : (ride ? focal_stream_kernel<4, true, true> : focal_stream_kernel<4, true, false>))
+                      : (u5 ? (ride ? focal_stream_kernel<5, false, true> : focal_stream_kernel<5, false, false>)
+                            : (ride ? focal_stream_kernel<4, false, true> : focal_stream_kernel<4, false, false>));
+      hipLaunchKernelGGL(kern, dim3(num_tiles * parts + ahead_blocks), dim3(kThreads), 0, s,
+                         classifications, d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
                          div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
-                         divisor, nrm.total, parts, part_vecs);
+                         divisor, nrm.total, parts, part_vecs, ahead);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
       auto kern = params->from_logits ? focal_rows_kernel<true> : focal_rows_kernel<false>;
@@ -1434,6 +1599,15 @@ int rh_focal_loss_fwd_bwd(const float* classifications, const float* regressions
                        w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n,
                        tile ? tile_parts(num_classes) : 0, kGenericBlocks, divisor, nrm.total);
     RH_CHECK_LAUNCH("finalize_kernel");
+  }
+  if (next) {
+    if (!next_assigned)
+      if (int e = launch_assign(anchors, next->annotations, batch, n, next->m, num_classes,
+                                params->neg_thresh, params->pos_thresh, wn, wn.code, nullptr,
+                                nullptr, nullptr, nullptr, next->status, s))
+        return e;
+    if (params->normalizer == RH_NORM_GLOBAL)
+      if (int e = launch_count(wn, batch, next->num_pos, s)) return e;
   }
   return RH_OK;
 }

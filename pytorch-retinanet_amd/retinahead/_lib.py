@@ -49,6 +49,18 @@ class FocalParams(C.Structure):
     ]
 
 
+class AssignAhead(C.Structure):
+    """rh_assign_ahead: the next step's assignment, carried by this step's stream launch."""
+    _fields_ = [
+        ("annotations", C.c_void_p),
+        ("m", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_size_t),
+        ("status", C.c_void_p),
+        ("num_pos", C.c_void_p),
+    ]
+
+
 NORM_PER_IMAGE, NORM_GLOBAL = 0, 1
 NORMALIZERS = {"per_image": NORM_PER_IMAGE, "global": NORM_GLOBAL}
 
@@ -88,6 +100,9 @@ SIGNATURES = {
                                                _I32, _P]),
     "rh_focal_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I32, _I32, C.POINTER(FocalParams),
                                         _P, _P, _P, _P, _P, _P, _P, _SZ, _I32, _P]),
+    "rh_focal_loss_fwd_bwd_ahead": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I32, _I32, C.POINTER(FocalParams),
+                                              _P, _P, _P, _P, _P, _P, _P, _SZ, _I32,
+                                              C.POINTER(AssignAhead), _P]),
     "rh_apply_upstream_f32": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _F, _P]),
     "rh_generic_focal_workspace_bytes": (_SZ, [_I64]),
     "rh_generic_focal_fwd_bwd": (C.c_int, [_P, _P, _I64, _F, _F, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),

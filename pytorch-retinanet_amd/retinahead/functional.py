@@ -298,10 +298,65 @@ def _build_focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch
                             float(grad_reg), int(batch_divisor), int(bool(from_logits)), norm, total)
 
 
+def _focal_ws_bytes(lib, bsz, n, c, m):
+    shape_key = (bsz, n, c, m)
+    need = _ws_bytes_cache.get(shape_key)
+    if need is None:
+        need = _ws_bytes_cache[shape_key] = lib.rh_focal_loss_workspace_bytes(bsz, n, c, m)
+    return need
+
+
+def new_small_outputs(bsz, dev):
+    """The small outputs of one loss call over ``bsz`` images, unwritten."""
+    return LossOutputs(small=torch.empty((_SMALL_HEAD + 4 * bsz,), dtype=torch.float32, device=dev))
+
+
+def focal_workspace(bsz, n, num_classes, m, dev):
+    """A workspace of its own for one loss step over [bsz, n, num_classes] with m annotation rows."""
+    need = _focal_ws_bytes(_lib.load(), bsz, n, int(num_classes), m)
+    if need == 0:
+        raise RetinaHeadError(f"unsupported shape B={bsz} N={n} C={num_classes} M={m}")
+    return torch.empty((need,), dtype=torch.uint8, device=dev)
+
+
+def focal_assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5,
+                 normalizer="per_image", ws=None, out=None):
+    """The assignment stage of a later ``focal_loss_fwd_bwd`` call, run now on the current stream:
+    it reads the anchors and the annotations only (losses.py:48-79), so a trainer can issue it for
+    the next batch on a second stream while the current step's stream stage runs.  Returns
+    ``(out, ws)``: the small outputs (status, and num_pos under the batch-wide normaliser, are
+    written) and the step's workspace, both to be handed to
+    ``focal_loss_fwd_bwd(..., stages=STAGE_STREAM | STAGE_FINALIZE, out=out, ws=ws)`` with the
+    same annotations, thresholds and normaliser.  ``ws``: a buffer to reuse (a uint8 tensor of at
+    least the workspace size), else a new one; ``out``: small outputs allocated by the caller
+    (``new_small_outputs``), e.g. on the stream that will run the rest of the step."""
+    dev = _dev_check(anchors_t, annotations)
+    anc, ann = _anchors2d(anchors_t), _f32c(annotations)
+    if ann.dim() != 3 or ann.shape[2] != 5:
+        raise RetinaHeadError("annotations must be [B,M,5]")
+    bsz, m, n, c = ann.shape[0], ann.shape[1], anc.shape[0], int(num_classes)
+    lib = _lib.load()
+    need = _focal_ws_bytes(lib, bsz, n, c, m)
+    if need == 0:
+        raise RetinaHeadError(f"unsupported shape B={bsz} N={n} C={c} M={m}")
+    if ws is None or ws.device != dev or ws.dtype != torch.uint8 or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    if out is None:
+        out = new_small_outputs(bsz, dev)
+    params = _focal_params(0.25, neg_thresh, pos_thresh, 1.0, 1.0, 0, False, normalizer, None, dev)
+    p_losses, p_per_image, p_num_pos, p_status = _small_ptrs(out, bsz)
+    with _on_device(dev) as stream:
+        _lib.check(lib.rh_focal_loss_fwd_bwd(
+            None, None, anc.data_ptr(), ann.data_ptr(), bsz, n, c, m, C.byref(params), None, None,
+            p_losses, p_per_image, p_num_pos, p_status, ws.data_ptr(), ws.numel(),
+            int(_lib.STAGE_ASSIGN), stream), "rh_focal_loss_fwd_bwd")
+    return out, ws
+
+
 def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alpha=0.25,
                        neg_thresh=0.4, pos_thresh=0.5, grad_cls=1.0, grad_reg=1.0,
                        batch_divisor=0, stages=_lib.STAGE_ALL, out=None, from_logits=False,
-                       normalizer="per_image", num_pos_total=None):
+                       normalizer="per_image", num_pos_total=None, ws=None, ahead=None):
     """Runs the fused loss kernels.  Returns a dict of device tensors:
     losses [2], exchange [4] (the losses, the call's positive anchors and its images: what
     data-parallel ranks sum), total [1] (the losses' sum), per_image [2,B], num_pos [B], status [B],
@@ -310,6 +365,12 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
     ``normalizer='global'``: one positive count for the whole batch instead of the reference's
     per-image counts and batch mean; ``num_pos_total`` (device float32 [1]) supplies a count
     formed elsewhere (over all ranks of a data-parallel job), else the call counts its own.
+    ``ws``: the step's workspace (uint8 tensor) when the caller keeps it, as ``focal_assign``
+    does for a step whose assignment ran ahead; else the stream's cached one.
+    ``ahead``: ``(annotations, ws, out)`` of the NEXT step -- its annotations [B,M',5], its
+    workspace (``focal_workspace``) and its small outputs (``new_small_outputs``): the next
+    step's assignment stage is carried by this call's stream launch, and the next call runs
+    ``stages=STAGE_STREAM | STAGE_FINALIZE`` with ``ws=`` and ``out=`` set to those.
     """
     dev = _dev_check(classifications, regressions, anchors_t, annotations)
     cls, reg = _f32c(classifications), _f32c(regressions)
@@ -331,20 +392,37 @@ def focal_loss_fwd_bwd(classifications, regressions, anchors_t, annotations, alp
             d_classifications=torch.empty_like(cls),
             d_regressions=torch.empty_like(reg),
         )
+    elif not dict.__contains__(out, "d_classifications"):    # from focal_assign: small outputs only
+        out["d_classifications"] = torch.empty_like(cls)
+        out["d_regressions"] = torch.empty_like(reg)
     params = _focal_params(alpha, neg_thresh, pos_thresh, grad_cls, grad_reg, batch_divisor,
                            from_logits, normalizer, num_pos_total, dev)
-    shape_key = (bsz, n, c, m)
-    need = _ws_bytes_cache.get(shape_key)
-    if need is None:
-        need = _ws_bytes_cache[shape_key] = lib.rh_focal_loss_workspace_bytes(bsz, n, c, m)
+    need = _focal_ws_bytes(lib, bsz, n, c, m)
+    if ws is not None and (ws.device != dev or ws.dtype != torch.uint8 or ws.numel() < need):
+        raise RetinaHeadError(f"ws must be a uint8 tensor of at least {need} bytes on {dev}")
     p_losses, p_per_image, p_num_pos, p_status = _small_ptrs(out, bsz)
     with _on_device(dev) as stream:
-        ws = workspace(dev, need, "focal", stream)
-        _lib.check(lib.rh_focal_loss_fwd_bwd(
-            cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), bsz, n, c, m,
-            C.byref(params), out["d_classifications"].data_ptr(), out["d_regressions"].data_ptr(),
-            p_losses, p_per_image, p_num_pos, p_status, ws.data_ptr(), ws.numel(), int(stages), stream),
-            "rh_focal_loss_fwd_bwd")
+        if ws is None:
+            ws = workspace(dev, need, "focal", stream)
+        if ahead is None:
+            _lib.check(lib.rh_focal_loss_fwd_bwd(
+                cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), bsz, n, c, m,
+                C.byref(params), out["d_classifications"].data_ptr(), out["d_regressions"].data_ptr(),
+                p_losses, p_per_image, p_num_pos, p_status, ws.data_ptr(), ws.numel(), int(stages), stream),
+                "rh_focal_loss_fwd_bwd")
+        else:
+            n_ann, n_ws, n_out = ahead
+            n_ann = _f32c(n_ann)
+            if n_ann.dim() != 3 or n_ann.shape[2] != 5 or n_ann.shape[0] != bsz or n_ann.device != dev:
+                raise RetinaHeadError("the next step's annotations must be [B,M,5] for the same B and device")
+            _, _, n_num_pos, n_status = _small_ptrs(n_out, bsz)
+            nxt = _lib.AssignAhead(n_ann.data_ptr(), n_ann.shape[1], n_ws.data_ptr(), n_ws.numel(),
+                                   n_status, n_num_pos)
+            _lib.check(lib.rh_focal_loss_fwd_bwd_ahead(
+                cls.data_ptr(), reg.data_ptr(), anc.data_ptr(), ann.data_ptr(), bsz, n, c, m,
+                C.byref(params), out["d_classifications"].data_ptr(), out["d_regressions"].data_ptr(),
+                p_losses, p_per_image, p_num_pos, p_status, ws.data_ptr(), ws.numel(), int(stages),
+                C.byref(nxt), stream), "rh_focal_loss_fwd_bwd_ahead")
     return out
 
 

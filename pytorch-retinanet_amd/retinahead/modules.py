@@ -106,6 +106,71 @@ class _CallState:
         return out
 
 
+class _AssignAhead:
+    """Assignments asked for ahead of their step (``FocalLoss.prefetch_assignment``).  Per device:
+    the request not yet carried out (it rides on the next ``forward``'s stream launch), the
+    assignment carried out and waiting for its step, and up to three workspaces that take turns.
+    Shared by the replicas nn.DataParallel makes; each works on its own device."""
+
+    def __init__(self):
+        self.by_device = {}
+        self.lock = threading.Lock()
+
+    def __reduce__(self):
+        return (_AssignAhead, ())
+
+    def _state(self, dev):
+        st = self.by_device.get(dev.index)
+        if st is None:
+            with self.lock:
+                st = self.by_device.setdefault(dev.index, {"bufs": [], "asked": None, "ready": None})
+        return st
+
+    @staticmethod
+    def key(anchors, annotations, num_classes, cfg):
+        return (annotations.data_ptr(), annotations._version, tuple(annotations.shape),
+                anchors.data_ptr(), tuple(anchors.shape), int(num_classes), cfg["neg_thresh"],
+                cfg["pos_thresh"], cfg["normalizer"])
+
+    def ask(self, anchors, annotations, num_classes, cfg):
+        # the tensor is kept alive so that its address cannot come to name another one
+        self._state(annotations.device)["asked"] = {
+            "key": self.key(anchors, annotations, num_classes, cfg), "ann": annotations}
+
+    def take(self, anchors, annotations, num_classes, cfg):
+        """The finished assignment of this step, if the previous step carried it."""
+        st = self.by_device.get(annotations.device.index)
+        if st is None:
+            return None
+        hit, st["ready"] = st["ready"], None
+        if hit is not None and hit["key"] == self.key(anchors, annotations, num_classes, cfg):
+            return hit
+        return None
+
+    def next_for(self, cls, anchors, using):
+        """What the step now starting carries for the next one: (annotations, workspace, small
+        outputs), or None.  ``using``: the workspace this step itself reads, if it is one of ours."""
+        st = self.by_device.get(cls.device.index)
+        asked = st and st["asked"]
+        if not asked:
+            return None
+        st["asked"] = None
+        key, ann = asked["key"], asked["ann"]
+        if (ann.dim() != 3 or ann.shape[0] != cls.shape[0] or key[5] != cls.shape[-1]
+                or key[3] != anchors.data_ptr() or ann._version != key[1]):
+            return None                 # another batch size, class count or anchor set: not ours
+        lib = _lib.load()
+        need = F._focal_ws_bytes(lib, cls.shape[0], cls.shape[1], cls.shape[2], ann.shape[1])
+        ws = next((b for b in st["bufs"] if b is not using and b.numel() >= need), None)
+        if ws is None:
+            ws = F.focal_workspace(cls.shape[0], cls.shape[1], cls.shape[2], ann.shape[1], cls.device)
+            st["bufs"].append(ws)
+            del st["bufs"][:-3]
+        out = F.new_small_outputs(cls.shape[0], cls.device)
+        st["ready"] = {"key": key, "ann": ann, "ws": ws, "out": out}
+        return ann, ws, out
+
+
 def _is_unit(g):
     """True when ``g`` is known on the host to hold exactly 1.0: it is the cached seed."""
     unit = _UNIT.get(g.device.index) if g is not None else None
@@ -165,6 +230,15 @@ def _run_fused(fn, tensors, cfg):
         total = hook(out["num_pos"])
         return fn(*tensors, stages=_lib.STAGE_STREAM | _lib.STAGE_FINALIZE, out=out,
                   num_pos_total=total, **kw)
+    ahead = cfg.get("ahead")
+    if ahead is not None and fn is F.focal_loss_fwd_bwd and ahead.by_device:
+        cls, _, anchors, annotations = tensors
+        hit = ahead.take(anchors, annotations, cls.shape[-1], cfg)
+        nxt = ahead.next_for(cls, anchors, hit["ws"] if hit else None)
+        if hit is not None:     # this step's assignment came with the previous step
+            return fn(*tensors, stages=_lib.STAGE_STREAM | _lib.STAGE_FINALIZE, out=hit["out"],
+                      ws=hit["ws"], ahead=nxt, **kw)
+        return fn(*tensors, ahead=nxt, **kw)
     return fn(*tensors, **kw)
 
 
@@ -278,8 +352,20 @@ class FocalLoss(nn.Module):
         self.cfg = dict(alpha=float(alpha), neg_thresh=float(neg_thresh),
                         pos_thresh=float(pos_thresh), expected_grad=float(expected_grad),
                         batch_divisor=int(batch_divisor), from_logits=bool(from_logits),
-                        normalizer=normalizer, reduce_total=None, state=_CallState())
+                        normalizer=normalizer, reduce_total=None, state=_CallState(),
+                        ahead=_AssignAhead())
         self.check_labels = bool(check_labels)
+
+    def prefetch_assignment(self, anchors, annotations, num_classes):
+        """Optional: names the annotations of the step AFTER the next ``forward`` call -- batch
+        i+1, announced before ``forward`` of batch i.  That call's kernel launch then also does
+        batch i+1's IoU assignment (losses.py:57-79, which needs no predictions): its [B,N,C]
+        stream waits on HBM and leaves the vector ALUs free, so the assignment costs about a
+        fifth of what it costs alone.  The later ``forward`` with the same ``annotations`` tensor
+        (unmodified), anchors, batch size and class count skips its assignment stage; any other
+        call computes its own, so results never depend on this method.  Not used by
+        ``forward_levels`` or when a ``reduce_total`` hook stages the call."""
+        self.cfg["ahead"].ask(anchors, annotations, num_classes, self.cfg)
 
     @property
     def last(self):

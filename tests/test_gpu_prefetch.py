@@ -1,0 +1,144 @@
+"""FocalLoss.prefetch_assignment: a step whose IoU assignment was carried by the previous step's
+stream launch gives the results of the plain step bit for bit -- in eager calls, when the
+announced tensor is not the one that arrives, and in two alternating captured graphs (the
+benchmark's launch mode)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import dev, make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rh():
+    import retinahead
+    retinahead.load_library()
+    return retinahead
+
+
+def run_step(mod, cls, reg, anc, ann):
+    cls = cls.detach().clone().requires_grad_(True)
+    reg = reg.detach().clone().requires_grad_(True)
+    out = mod(cls, reg, anc, ann)
+    sum(out.values()).backward()
+    return (out["classification_loss"].detach().clone(), out["regression_loss"].detach().clone(),
+            cls.grad.clone(), reg.grad.clone(), mod.last["num_pos"].clone(), mod.last["status"].clone())
+
+
+def same(a, b):
+    return all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.fixture
+def stages_seen(rh, monkeypatch):
+    seen = []
+    real = rh.functional.focal_loss_fwd_bwd
+
+    def spy(*a, **kw):
+        seen.append((kw.get("stages", rh._lib.STAGE_ALL), kw.get("ahead") is not None))
+        return real(*a, **kw)
+    monkeypatch.setattr(rh.functional, "focal_loss_fwd_bwd", spy)
+    return seen
+
+
+@pytest.mark.parametrize("normalizer,m", [("per_image", 6), ("global", 6), ("per_image", 200)])
+def test_prefetched_assignment_gives_the_plain_step(rh, stages_seen, normalizer, m):
+    """m = 200: annotation lists long enough for the split form of the assignment kernel, which
+    does not ride on the stream launch but follows it."""
+    size, c = 160, 20
+    batches = [make_batch(50 + i, 3, size, c, m, [m, 0, 2]) for i in range(4)]
+    anc = dev(batches[0][2])
+    data = [(dev(b[0]), dev(b[1]), dev(b[3])) for b in batches]
+    plain = rh.FocalLoss(normalizer=normalizer)
+    want = [run_step(plain, cls, reg, anc, ann) for cls, reg, ann in data]
+    del stages_seen[:]
+
+    mod = rh.FocalLoss(normalizer=normalizer)
+    later = rh._lib.STAGE_STREAM | rh._lib.STAGE_FINALIZE
+    for i, (cls, reg, ann) in enumerate(data):
+        if i + 1 < len(data):
+            mod.prefetch_assignment(anc, data[i + 1][2], c)      # carried by this step
+        got = run_step(mod, cls, reg, anc, ann)
+        assert same(got, want[i]), i
+        assert stages_seen[-1] == (rh._lib.STAGE_ALL if i == 0 else later, i + 1 < len(data))
+    st = mod.cfg["ahead"].by_device[anc.device.index]
+    assert st["ready"] is None and st["asked"] is None and len(st["bufs"]) <= 3
+
+
+def test_prefetch_that_does_not_match_is_ignored(rh):
+    size, c = 128, 8
+    b0, b1 = make_batch(60, 2, size, c, 4, [4, 1]), make_batch(61, 2, size, c, 4, [2, 3])
+    anc = dev(b0[2])
+    cls, reg, ann0, ann1 = dev(b0[0]), dev(b0[1]), dev(b0[3]), dev(b1[3])
+    plain = rh.FocalLoss()
+    want0, want1 = run_step(plain, cls, reg, anc, ann0), run_step(plain, cls, reg, anc, ann1)
+    assert not same(want0, want1)
+    mod = rh.FocalLoss()
+    mod.prefetch_assignment(anc, ann1, c)
+    assert same(run_step(mod, cls, reg, anc, ann0), want0)       # carries ann1's assignment
+    assert same(run_step(mod, cls, reg, anc, ann0), want0)       # but ann0 arrives again
+    mod.prefetch_assignment(anc, ann0, c)
+    assert same(run_step(mod, cls, reg, anc, ann1), want1)       # carries ann0's
+    ann0.copy_(ann1)                                             # modified after that
+    assert same(run_step(mod, cls, reg, anc, ann0), want1)
+    # an out-of-range label is still reported by the step that owns the annotations
+    bad = ann1.clone()
+    bad[0, 0, 4] = c
+    chk = rh.FocalLoss(check_labels=True)
+    chk.prefetch_assignment(anc, bad, c)
+    chk(cls, reg, anc, ann1)                                     # carries the bad batch: no error yet
+    with pytest.raises(IndexError):
+        chk(cls, reg, anc, bad)
+    # a batch of another size is not carried
+    mod.prefetch_assignment(anc, ann1[:1], c)
+    assert same(run_step(mod, cls, reg, anc, ann1), want1)
+    assert mod.cfg["ahead"].by_device[anc.device.index]["ready"] is None
+
+
+def test_prefetch_in_two_alternating_graphs(rh):
+    """Graph A runs step i on workspace X and assigns step i+1 into Y; graph B the reverse.  Replayed A, B, A, ... on changing data they give the plain results."""
+    size, c = 128, 20
+    batches = [make_batch(70 + i, 2, size, c, 5, [5, 2]) for i in range(6)]
+    anc = dev(batches[0][2])
+    s_cls = dev(batches[0][0]).requires_grad_(True)
+    s_reg = dev(batches[0][1]).requires_grad_(True)
+    # step i reads s_ann[i % 2]; while it runs, the other buffer holds step i+1's annotations
+    s_ann = [dev(batches[0][3]), dev(batches[1][3])]
+    mod = rh.FocalLoss()
+
+    def step(i):
+        s_cls.grad = None
+        s_reg.grad = None
+        mod.prefetch_assignment(anc, s_ann[(i + 1) % 2], c)
+        out = mod(s_cls, s_reg, anc, s_ann[i % 2])
+        sum(out.values()).backward()
+        return out["classification_loss"], out["regression_loss"], s_cls.grad, s_reg.grad
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):
+            step(i)              # leaves the assignment of s_ann[0] done, in its workspace
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graphs, outs = [], []
+    for i in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            outs.append(step(i))
+        graphs.append(g)
+    plain = rh.FocalLoss()
+    # the assignment of batch 0 must be in place before the first replay: it was issued by the
+    # eager steps above for s_ann[0], whose content is still batch 0's
+    for i in range(len(batches) - 1):
+        s_cls.data.copy_(dev(batches[i][0]))
+        s_reg.data.copy_(dev(batches[i][1]))
+        s_ann[(i + 1) % 2].copy_(dev(batches[i + 1][3]))
+        graphs[i % 2].replay()
+        torch.cuda.synchronize()
+        want = run_step(plain, dev(batches[i][0]), dev(batches[i][1]), anc, dev(batches[i][3]))
+        got = outs[i % 2]
+        for k in range(4):
+            assert torch.equal(got[k], want[k]), (i, k)
