@@ -438,6 +438,12 @@ struct SortSrc {
   // [B, A*4, H, W] of `lv`
   int tiles_per_image;
   LevelGeom lv;
+  // from_tiles != 0 and list_key != nullptr: topk_select_kernel has already copied the
+  // candidates that can reach the top-k out of the tile lists: image j's are
+  // list_key / list_lab [j*cap .. j*cap + list_count[j]), in no particular order
+  const u64* list_key;
+  const int* list_lab;
+  const int* list_count;
 };
 
 // First and last tile list of image j.
@@ -652,6 +658,204 @@ __global__ __launch_bounds__(kSortThreads) void sort_lds_kernel(int* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Top-k pre-selection (one workgroup per image), for calls that keep far fewer candidates than
+// the score scan finds (pre_nms_topk = 1000 of ~5600 at 1024 px): ranking a key costs a pass
+// over the whole list, so the list is first cut down to the keys that can reach the top-k.
+// A histogram over the upper bits of the scores (bins of 2^16 float32 steps, 1/128 of a binade;
+// the bin is a non-decreasing function of the score) gives the lowest bin b* such that the bins
+// from b* up hold at least topk keys; every key below b* has a smaller score than topk others
+// and cannot be among the top-k, whatever the tie-break.  The keys from b* up (topk of them
+// plus the rest of bin b*) are copied out in tile order -- anchor order but for the order inside
+// a tile, which is what the pair kernel's culling likes -- and their ranks among themselves are
+// their ranks among all.
+// counters [j] = candidates found, [batch + j] = selected keys that did not fit `cap`.
+// ---------------------------------------------------------------------------
+constexpr int kSelThreads = 1024;
+constexpr int kSelWaves = kSelThreads / 64;
+constexpr int kSelBins = 640;            // scores 1/32 (0x3D000000) .. 1 (0x3F800000), bits >> 16
+constexpr int kSelTiles = 3, kSelSlots = 8;
+// The upper half of a key is the score in its order-preserving form (sign bit set for positive
+// floats), so its top 16 bits order the keys like the scores; below 1/32 everything is bin 0.
+__device__ __forceinline__ int score_bin(const u64 key) {
+  const int b = (int)(key >> 48) - (int)((0x3D000000u ^ 0x80000000u) >> 16);
+  return min(max(b, 0), kSelBins - 1);
+}
+
+// Wave w owns a contiguous run of the image's tiles; lane l holds tiles run + u*64 + l for
+// u < kSelTiles (consecutive lanes, consecutive tiles: coalesced loads -- with a run of
+// consecutive tiles per THREAD the one compute unit that serves an image spent 8 us issuing
+// partly used cache lines), the first kSelSlots list entries of each, requested together with
+// the tile counts (one trip to memory, whatever the counts turn out to be) and kept in
+// registers for all three passes of the kernel.  The rare rest (longer tile lists, longer runs:
+// images beyond 3072 tiles) is fetched again by each pass.
+struct SelectHeld {
+  int c[kSelTiles];
+  u64 k[kSelTiles][kSelSlots];
+  int l[kSelTiles][kSelSlots];
+};
+
+struct SelectRun {
+  int wb, we;       // the wave's tiles [wb, we)
+  long long first, last;
+};
+
+// fn(key, label) for the candidates of held tile u (this image's only).
+template <typename F>
+__device__ __forceinline__ void select_visit_held(const SelectHeld& h, const int u,
+                                                  const TileCands& tc, const SelectRun& run,
+                                                  F&& fn) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < kSelSlots; ++r) {
+    const long long g = key_index(h.k[u][r]);
+    if (r < h.c[u] && g >= run.first && g <= run.last) fn(h.k[u][r], h.l[u][r]);
+  }
+  for (int r = kSelSlots; r < h.c[u]; ++r) {
+    const size_t o = tc.at(run.wb + u * 64 + lane, r);
+    const u64 k = tc.key[o];
+    const long long g = key_index(k);
+    if (g >= run.first && g <= run.last) fn(k, tc.lab[o]);
+  }
+}
+
+// ... and for the lane's tiles beyond the held ones.
+template <typename F>
+__device__ __forceinline__ void select_visit_rest(const TileCands& tc, const SelectRun& run, F&& fn) {
+  for (int t = run.wb + kSelTiles * 64 + (int)(threadIdx.x & 63); t < run.we; t += 64) {
+    const int c = tc.cnt[t];
+    for (int r = 0; r < c; ++r) {
+      const size_t o = tc.at(t, r);
+      const u64 k = tc.key[o];
+      const long long g = key_index(k);
+      if (g >= run.first && g <= run.last) fn(k, tc.lab[o]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kSelThreads) void topk_select_kernel(
+    int* __restrict__ counters, int batch, int cap, int topk, SortSrc src, u64* __restrict__ sel_key,
+    int* __restrict__ sel_lab, int* __restrict__ sel_count) {
+  __shared__ int s_hist[kSelBins];
+  __shared__ int s_wtot[kSelWaves];
+  __shared__ int s_bstar, s_kept;
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TileCands tc = src.tc;
+  int t_lo, t_hi;
+  image_tiles(src, j, t_lo, t_hi);
+  SelectRun run;
+  run.first = (long long)j * src.N;
+  run.last = run.first + src.N - 1;
+  const int chunk = ((t_hi - t_lo + kSelThreads) / kSelThreads) * 64;
+  run.wb = min(t_lo + wave * chunk, t_hi + 1);
+  run.we = min(run.wb + chunk, t_hi + 1);
+  RH_TL(0, 5);
+  SelectHeld h;
+#pragma unroll
+  for (int u = 0; u < kSelTiles; ++u) {
+    const int t = min(run.wb + u * 64 + lane, t_hi);
+    h.c[u] = tc.cnt[t];
+#pragma unroll
+    for (int r = 0; r < kSelSlots; ++r) {
+      h.k[u][r] = tc.key[tc.at(t, r)];
+      h.l[u][r] = tc.lab[tc.at(t, r)];
+    }
+  }
+  for (int b = tid; b < kSelBins; b += kSelThreads) s_hist[b] = 0;
+  if (tid == 0) {
+    s_bstar = 0;
+    s_kept = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kSelTiles; ++u)
+    if (run.wb + u * 64 + lane >= run.we) h.c[u] = 0;
+  RH_TL(0, 6);
+  auto count_bin = [&](const u64 key, int) { atomicAdd(&s_hist[score_bin(key)], 1); };
+#pragma unroll
+  for (int u = 0; u < kSelTiles; ++u) select_visit_held(h, u, tc, run, count_bin);
+  select_visit_rest(tc, run, count_bin);
+  __syncthreads();
+  RH_TL(0, 7);
+  // S(b) = keys in bins >= b; b* = the highest b with S(b) >= topk (bin 0 when there are fewer)
+  int suf = 0;
+  if (wave < kSelBins / 64) {
+    suf = s_hist[wave * 64 + lane];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_down(suf, d, 64);
+      if (lane + d < 64) suf += o;
+    }
+    if (lane == 0) s_wtot[wave] = suf;
+  }
+  __syncthreads();
+  int above = 0, found = 0;
+#pragma unroll
+  for (int w = 0; w < kSelBins / 64; ++w) {
+    above += w > wave ? s_wtot[w] : 0;
+    found += s_wtot[w];
+  }
+  if (wave < kSelBins / 64) {
+    const unsigned long long reach = __ballot(above + suf >= topk);
+    if (reach != 0ull && lane == 63 - __builtin_clzll(reach)) atomicMax(&s_bstar, wave * 64 + lane);
+  }
+  __syncthreads();
+  const int bstar = s_bstar;
+  if (wave == bstar / 64 && lane == bstar % 64) s_kept = above + suf;     // S(b*)
+  RH_TL(0, 8);
+  // List positions, in the order tile group 0 (lane 0..63), group 1, ..., then the rest per lane:
+  // tile order as long as the held tiles cover the run.
+  int kc[kSelTiles + 1], at[kSelTiles + 1];
+#pragma unroll
+  for (int u = 0; u <= kSelTiles; ++u) kc[u] = 0;
+#pragma unroll
+  for (int u = 0; u < kSelTiles; ++u)
+    select_visit_held(h, u, tc, run, [&](const u64 key, int) { kc[u] += score_bin(key) >= bstar; });
+  select_visit_rest(tc, run, [&](const u64 key, int) { kc[kSelTiles] += score_bin(key) >= bstar; });
+  int wave_total = 0;
+#pragma unroll
+  for (int u = 0; u <= kSelTiles; ++u) {
+    int incl = kc[u];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    at[u] = wave_total + incl - kc[u];
+    wave_total += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) s_wtot[wave] = wave_total;      // (its earlier readers are past the barrier above)
+  __syncthreads();
+  int wave_base = 0;
+#pragma unroll
+  for (int w = 0; w < kSelWaves; ++w) wave_base += w < wave ? s_wtot[w] : 0;
+  RH_TL(0, 9);
+  u64* kj = sel_key + (size_t)j * cap;
+  int* lj = sel_lab + (size_t)j * cap;
+#pragma unroll
+  for (int u = 0; u <= kSelTiles; ++u) {
+    int pos = wave_base + at[u];
+    auto put = [&](const u64 key, const int lab) {
+      if (score_bin(key) >= bstar) {
+        if (pos < cap) {
+          kj[pos] = key;
+          lj[pos] = lab;
+        }
+        ++pos;
+      }
+    };
+    if (u < kSelTiles) select_visit_held(h, u < kSelTiles ? u : 0, tc, run, put);
+    else select_visit_rest(tc, run, put);
+  }
+  RH_TL(0, 10);
+  if (tid == 0) {
+    const int kept = s_kept;
+    sel_count[j] = kept;
+    counters[j] = found;
+    counters[batch + j] = max(kept - cap, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Rank sort for candidate lists of up to kRankMax keys per image.  Keys are unique (the
 // index is part of the key), so a key's position in descending order is the number of keys
 // greater than it: no exchange network, no serial dependency, and the work spreads over the
@@ -730,7 +934,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   const int p0 = blockIdx.y * kRankKeys;
   RH_TL(0, 0);
   int found;
-  if (src.from_tiles) {
+  if (src.from_tiles && !src.list_key) {
     const TileCands tc = src.tc;
     const long long first = (long long)j * src.N, last = first + src.N - 1;
     int t_lo, t_hi;
@@ -839,6 +1043,15 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
         }
       }
     }
+  } else if (src.list_key) {
+    found = src.list_count[j];
+    if (p0 >= min(found, cap) && blockIdx.y != 0) return;
+    for (int i = tid; i < min(found, cap); i += kRankThreads) {
+      const u64 k = src.list_key[(size_t)j * cap + i];
+      s_sk[i] = (unsigned)(k >> 32);
+      s_ix[i] = (unsigned)k;
+      s_lab[i] = src.list_lab[(size_t)j * cap + i];
+    }
   } else {
     found = src.count;
     if (p0 >= min(found, cap) && blockIdx.y != 0) return;
@@ -860,7 +1073,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   const int seg = ((K + 8 * kRankWaves - 1) / (8 * kRankWaves)) << 3;
   const int q0 = min(wave * seg, K), q1 = min(q0 + seg, K);
   int rank;
-  if (src.from_tiles && src.tiles_per_image > 0) {
+  if (src.from_tiles && (src.tiles_per_image > 0 || src.list_key)) {
     rank = rank_count<2>(s_sk, s_ix, q0, q1, mys, myx);      // list not in anchor order: full keys
   } else {
     rank = rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx);
@@ -910,8 +1123,10 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
       out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
     }
     if (blockIdx.y == 0 && lane == 0) {
-      counters[j] = found;
-      counters[batch + j] = max(found - cap, 0);
+      if (!src.list_key) {           // (the selection kernel has written these two)
+        counters[j] = found;
+        counters[batch + j] = max(found - cap, 0);
+      }
       counters[2 * batch + j] = ke;
     }
     RH_TL(0, 4);
@@ -1110,9 +1325,10 @@ struct PairLane {
 template <bool kPerClass>
 __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
     const float4* __restrict__ cbox, const int4* __restrict__ cinfo,
-    const float4* __restrict__ csum, const int* __restrict__ counters, int batch,
-    u64* __restrict__ mask, u64* __restrict__ nz, int cap, int list_stride, int clusters,
-    int box_stride, int wstride, int nzw, int slices, float thresh, int ranked) {
+    const float4* __restrict__ csum, const int* __restrict__ counters,
+    const int* __restrict__ list_len, int batch, u64* __restrict__ mask, u64* __restrict__ nz,
+    int cap, int list_stride, int clusters, int box_stride, int wstride, int nzw, int slices,
+    float thresh, int ranked) {
   // one-dimensional grid, the image index fastest: the workgroups of clusters beyond an image's
   // list (most of the grid when the lists are far from full) come last and exit at once
   const int j = blockIdx.x % batch;
@@ -1143,7 +1359,9 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
   const float4 b_box0 = sj[first_b * 2], b_rng0 = sj[first_b * 2 + 1];
   __builtin_amdgcn_sched_barrier(0);
   // ranked: the list is what the rank sort saw; else the boxes are in rank order themselves
-  const int klist = ranked ? min(counters[j], cap) : counters[2 * batch + j];
+  // (list_len: the entries the rank sort was given -- all candidates found, or those the
+  // top-k pre-selection kept)
+  const int klist = ranked ? min(list_len[j], cap) : counters[2 * batch + j];
   const int C = (klist + 63) >> 6;
   RH_TL(1, 1);
   if (A >= C) return;
@@ -1643,6 +1861,7 @@ struct NmsPlan {
   int wstride;      // mask words per box
   int nzw;          // words of a box's bitmap of non-zero mask words
   bool ranked;      // the rank sort runs: list-order arrays exist
+  bool select;      // a top-k pre-selection cuts the candidate lists down first
   int clusters;     // clusters of 64 list entries (ranked) or 64 ranks (not ranked)
 };
 
@@ -1656,6 +1875,9 @@ static NmsPlan make_plan(int batch, long long cap, int topk) {
   p.wstride = (p.box_cap + 63) / 64;
   p.nzw = (p.wstride + 63) / 64;
   p.ranked = p.cap <= kRankMax;
+  // worth its launch when at most half the room can pass (measured at 1024 px, 5600 candidates,
+  // top-1000: the rank sort alone 36 us, selection + rank sort of the ~1100 kept 16 us)
+  p.select = p.ranked && topk > 0 && 2ll * topk <= cap;
   p.clusters = ((p.ranked ? p.cap : p.box_cap) + 63) / 64;
   return p;
 }
@@ -1681,6 +1903,9 @@ struct PostWorkspace {
   float4* cbox;      // [B][cap] boxes in list order (rank sort only)
   int4* cinfo;       // [B][cap] (rank or -1, label) in list order (rank sort only)
   float4* csum;      // [B][clusters][2] bounding box and area range of each cluster
+  u64* sel_key;      // [B][cap] keys kept by the top-k pre-selection, their labels, their number
+  int* sel_lab;
+  int* sel_count;
   size_t bytes;
 };
 
@@ -1699,6 +1924,9 @@ static PostWorkspace carve_post(void* ws, const NmsPlan& p, long long num_tiles)
   w.cbox = cv.take<float4>(p.ranked ? (size_t)p.batch * p.cap : 0);
   w.cinfo = cv.take<int4>((size_t)p.batch * (p.ranked ? p.cap : p.box_cap));
   w.csum = cv.take<float4>((size_t)p.batch * p.clusters * 2);
+  w.sel_key = cv.take<u64>(p.select ? (size_t)p.batch * p.cap : 0);
+  w.sel_lab = cv.take<int>(p.select ? (size_t)p.batch * p.cap : 0);
+  w.sel_count = cv.take<int>(p.select ? (size_t)p.batch : 0);
   w.bytes = cv.off;
   return w;
 }
@@ -1735,10 +1963,19 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
                        hipStream_t s) {
   const SortOut so = sort_out(p, w);
   if (p.ranked) {
+    SortSrc from = src;
+    if (p.select && src.from_tiles) {
+      hipLaunchKernelGGL(topk_select_kernel, dim3(p.batch), dim3(kSelThreads), 0, s, w.counters,
+                         p.batch, p.cap, topk, src, w.sel_key, w.sel_lab, w.sel_count);
+      RH_CHECK_LAUNCH("topk_select_kernel");
+      from.list_key = w.sel_key;
+      from.list_lab = w.sel_lab;
+      from.list_count = w.sel_count;
+    }
     const size_t lds = rank_lds_bytes(p.cap);
     if (int e = allow_lds(sort_rank_kernel, lds)) return e;
     hipLaunchKernelGGL(sort_rank_kernel, dim3(p.batch, (p.cap + kRankKeys - 1) / kRankKeys),
-                       dim3(kRankThreads), lds, s, w.counters, p.batch, p.cap, topk, src, so);
+                       dim3(kRankThreads), lds, s, w.counters, p.batch, p.cap, topk, from, so);
     RH_CHECK_LAUNCH("sort_rank_kernel");
     return RH_OK;
   }
@@ -1784,7 +2021,8 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
     RH_REQUIRE((long long)p.clusters * slices * p.batch < (1ll << 31), RH_ESHAPE, "too many NMS workgroups");
     auto kern = per_class ? nms_pairs_kernel<true> : nms_pairs_kernel<false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.clusters * slices * p.batch)), dim3(kThreads), 0, s,
-                       p.ranked ? w.cbox : w.sbox, w.cinfo, w.csum, w.counters, p.batch, w.mask, w.nz,
+                       p.ranked ? w.cbox : w.sbox, w.cinfo, w.csum, w.counters,
+                       p.select ? w.sel_count : w.counters, p.batch, w.mask, w.nz,
                        p.cap, p.ranked ? p.cap : p.box_cap, p.clusters, p.box_cap, p.wstride, p.nzw,
                        slices, thresh, p.ranked ? 1 : 0);
     RH_CHECK_LAUNCH("nms_pairs_kernel");

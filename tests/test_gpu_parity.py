@@ -1013,6 +1013,28 @@ def test_postprocess_per_class_topk_maxdet(rh):
     check_post(rh, cls, reg, anc, 192, pre_nms_topk=1000, max_det=50)
 
 
+def test_postprocess_topk_preselection(rh):
+    """pre_nms_topk at most half the candidate room goes through the histogram pre-selection:
+    heavy score ties (the bin that straddles the cut holds hundreds of equal scores, resolved by
+    anchor index), fewer candidates than the top-k, and a cut deep inside the list."""
+    cls, reg, anc = infer_batch(11, 2, 256, 20, mu=-3.5)
+    tied = np.round(cls * 16) / 16                     # scores on a grid of 1/16: 0.0625, 0.125, ...
+    tied[1] = np.where(tied[1] > 0.1, 0.25, tied[1])   # image 1: one value for nearly everything
+    res = check_post(rh, tied.astype(np.float32), reg, anc, 256, pre_nms_topk=500)
+    check_post(rh, tied.astype(np.float32), reg, anc, 256, pre_nms_topk=500, mode="per_class")
+    check_post(rh, cls, reg, anc, 256, pre_nms_topk=2000)       # more than an image has: all pass
+    check_post(rh, cls, reg, anc, 256, pre_nms_topk=64)
+    check_post(rh, cls, reg, anc, 256, pre_nms_topk=1, max_det=1)
+    assert all(r["scores"].numel() > 0 for r in res)
+    # candidate counts: everything over the threshold is still reported
+    raw = rh.functional.postprocess_raw(dev(cls), dev(reg), dev(anc), 256, 256, pre_nms_topk=64)
+    over = (cls.max(axis=2) > 0.05).sum(axis=1)
+    assert np.array_equal(raw["counts"][1].cpu().numpy(), over)
+    # ... and although they are three times the room (4096 per image), nothing is dropped: only
+    # the few hundred keys from the cut's histogram bin up are ever stored
+    assert int(over.min()) > 3 * 4096 - 100 and int(raw["counts"][2].max()) == 0
+
+
 def test_postprocess_overflow_retry_and_odd_classes(rh):
     cls, reg, anc = infer_batch(3, 2, 128, 601, mu=-7.0)
     check_post(rh, cls, reg, anc, 128, max_candidates=64)      # forces the exact second pass

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--logits", action="store_true", help="loss on logits (sigmoid folded in)")
     ap.add_argument("--levels", action="store_true", help="loss on the heads' [B, A*C, H, W] outputs")
     ap.add_argument("--shape", help="B,size,C,M instead of --cfg")
+    ap.add_argument("--topk", type=int, default=0, help="pre-NMS top-k (post-processing)")
+    ap.add_argument("--cap", type=int, default=4096, help="candidate capacity per image (post-processing)")
     a = ap.parse_args()
     bsz, size, c, m = [int(x) for x in a.shape.split(",")] if a.shape else CFG[a.cfg]
     dev = torch.device("cuda:0")
@@ -98,13 +100,13 @@ def main():
                 extra = f"  algo {algo / mean / 1e6:8.1f} GB/s" if name in ("decode", "all") else ""
                 print(f"{name:9s} mean {mean * 1e3:8.1f} us  min {mn * 1e3:8.1f} us{extra}")
             return
-        res = F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=4096)
+        res = F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=a.cap, pre_nms_topk=a.topk)
         print("counts", res["counts"].cpu().numpy()[:, :4].tolist())
         algo = bsz * n * (4 * c + 32)
         for name, st in (("decode", _lib.POST_DECODE), ("sort", _lib.POST_SORT),
                          ("nms", _lib.POST_NMS), ("all", _lib.POST_ALL)):
-            fn = lambda: F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=4096, stages=st,
-                                           out=res)
+            fn = lambda: F.postprocess_raw(icls, ireg, anchors, size, size, cand_cap=a.cap, stages=st,
+                                           pre_nms_topk=a.topk, out=res)
             for _ in range(5):
                 fn()
             mean, mn = bench.event_times(fn, a.iters)

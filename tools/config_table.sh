@@ -1,19 +1,30 @@
 #!/bin/bash
 # usage (on the GPU box): tools/config_table.sh > gpurun_out/configs.txt
 # Kernel averages (rocprofv3 --kernel-trace --stats) of the loss and post-processing stages for the
-# benchmark configurations: B,size,C,M = 2,512,600,10 | 16,608,80,20 | 8,800,601,8 | 4,1024,80,256.
+# benchmark configurations: B,size,C,M = 2,512,600,10 | 16,608,80,20 | 8,800,601,8 | 4,1024,80,256
+# (the last with its top-1000 pre-NMS selection and room for its ~5600 candidates per image).
 cd /tmp && export TMPDIR=/tmp
 for shape in 2,512,600,10 16,608,80,20 8,800,601,8 4,1024,80,256; do
   for mode in "" "--infer"; do
+    extra=""
+    if [ "$mode" = "--infer" ] && [ "$shape" = "4,1024,80,256" ]; then extra="--topk 1000 --cap 8192"; fi
     d=$GRAFT_REPO_ROOT/gpurun_out/cfgtab; rm -rf $d; mkdir -p $d
+    # whole call by HIP events in a run of its own: under the profiler the host enqueues slower
+    # than the GPU works through these few short kernels
+    timeout -k 10 120 python3 $GRAFT_REPO_ROOT/tools/bench_stages.py --shape $shape --iters 200 $mode $extra > $d/plain.log 2>&1 || exit 1
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- \
-      python3 $GRAFT_REPO_ROOT/tools/bench_stages.py --shape $shape --iters 40 $mode > $d/run.log 2>&1 || exit 1
+      python3 $GRAFT_REPO_ROOT/tools/bench_stages.py --shape $shape --iters 40 $mode $extra > $d/run.log 2>&1 || exit 1
     python3 - "$shape" "$mode" $d <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[3] + "/*/*kernel_stats.csv")[0]
 rows = [r for r in csv.DictReader(open(f)) if "rh::" in r["Name"] and "anchors_level" not in r["Name"]]
+import re
+log = open(sys.argv[3] + "/plain.log").read()
+m = re.search(r"^all\s+mean\s+([0-9.]+) us\s+min\s+([0-9.]+) us", log, re.M)
+total = sum(float(r["AverageNs"]) for r in rows) / 1e3
+whole = f" | kernels together {total:.1f} us | whole call, one stream, HIP events: mean {m.group(1)} min {m.group(2)} us" if m else ""
 print(f"B,size,C,M = {sys.argv[1]:16s} {'post-processing' if sys.argv[2] else 'loss':16s}",
-      " | ".join(f"{r['Name'].split('(')[0].split('rh::')[-1][:28]} {float(r['AverageNs'])/1e3:.1f} us" for r in rows))
+      " | ".join(f"{r['Name'].split('(')[0].split('rh::')[-1][:28]} {float(r['AverageNs'])/1e3:.1f} us" for r in rows) + whole)
 PY
   done
 done

@@ -40,12 +40,13 @@ for bsz in (1, 2, 5, 16):
     cls = (1 / (1 + np.exp(-rng.normal(-5.5, 1.2, (bsz, n, c))))).astype(np.float32)
     reg = rng.normal(0, 0.5, (bsz, n, 4)).astype(np.float32)
     tc, tr, ta = torch.from_numpy(cls).cuda(), torch.from_numpy(reg).cuda(), torch.from_numpy(anc).cuda()
-    for cap in (4096, 1024):
-        out = rh.functional.postprocess_raw(tc, tr, ta, size, size, cand_cap=cap)
+    for cap, topk in ((4096, 0), (1024, 0), (4096, 300), (4096, 1000)):
+        out = rh.functional.postprocess_raw(tc, tr, ta, size, size, cand_cap=cap, pre_nms_topk=topk)
         cnt = out["counts"].cpu().numpy()
         boxes_all = rh.ClipBoxes()(rh.BBoxTransform()(ta, tr), torch.zeros(1, 3, size, size, device="cuda")).cpu().numpy()
         for j in range(bsz):
-            so, lo, bo = O.postprocess_image(cls[j], reg[j], anc, size, size, boxes=boxes_all[j])
+            so, lo, bo = O.postprocess_image(cls[j], reg[j], anc, size, size, boxes=boxes_all[j],
+                                             pre_nms_topk=topk or None)
             kk = int(cnt[0, j])
             ok = kk == len(so) and np.array_equal(out["scores"][j, :kk].cpu().numpy(), so)
-            print(f"post B={bsz} cap={cap} image {j}: cands {cnt[1, j]} overflow {cnt[2, j]} kept {kk} want {len(so)}", "ok" if ok else "DIFF", flush=True)
+            print(f"post B={bsz} cap={cap} topk={topk} image {j}: cands {cnt[1, j]} overflow {cnt[2, j]} kept {kk} want {len(so)}", "ok" if ok else "DIFF", flush=True)

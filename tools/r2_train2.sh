@@ -1,12 +1,13 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/r2_fin
-mkdir -p $out
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/time_finalize.py > $out/run.log 2>&1 || { tail $out/run.log; exit 1; }
-python3 - "$out" <<'PY'
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_stats.csv')[0]
-for r in list(csv.DictReader(open(f)))[:6]:
-    print(f"{r['Name'][:64]:64s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} min={float(r['MinNs'])/1e3:9.2f} max={float(r['MaxNs'])/1e3:9.2f}")
+cd $GRAFT_REPO_ROOT
+for per in 1 4; do
+cp pytorch-retinanet_amd/retinahead/libretinahead.so /tmp/keep.so
+cp pytorch-retinanet_amd/csrc/build/libretinahead_per$per.so pytorch-retinanet_amd/retinahead/libretinahead.so
+timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2_bench_per$per.json 2> gpurun_out/r2_bench_1.err || { tail -20 gpurun_out/r2_bench_1.err; exit 1; }
+cp /tmp/keep.so pytorch-retinanet_amd/retinahead/libretinahead.so
+python - per$per <<'PY'
+import json,sys
+d=json.loads(open(f"gpurun_out/r2_bench_{sys.argv[1]}.json").read().strip().splitlines()[-1])
+print(sys.argv[1], "ms/step %.4f p10/p90 %s stream %.4f assign %.4f" % (d["ms_per_step"], d["ms_per_step_p10_p90"], d["roofline"]["kernel_ms_mean"], d["kernels_ms"]["assign_stage"]))
 PY
-rm -rf $out/*/
+done
