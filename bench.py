@@ -342,6 +342,17 @@ def main():
         for _ in range(10):
             stream_fn()
         k1_mean, k1_min = event_times(stream_fn, 100)
+        plain_mean, plain_min = event_train(stream_fn, 20, 10)
+        if prefetch:
+            # the launch as the timed steps issue it: with the next step's assignment workgroups
+            # at the end of its grid
+            next_ws = F.focal_workspace(BATCH, n, CLASSES, ann.shape[1], dev)
+            next_out = F.new_small_outputs(BATCH, dev)
+            stream_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann,
+                                                     stages=_lib.STAGE_STREAM, out=bufs,
+                                                     ahead=(ann, next_ws, next_out))
+            for _ in range(10):
+                stream_fn()
         k_mean, k_min = event_train(stream_fn, 20, 10)
         k_p10, k_p50, k_p90 = (float(np.percentile(event_train.last, q)) for q in (10, 50, 90))
         assign_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann,
@@ -356,10 +367,13 @@ def main():
     # but only while it names the kernel sources it was measured on.
     traffic, traffic_note = None, "no PMC summary"
     tfile = os.path.join(ROOT, "profiles", "traffic_focal_stream.json")
+    variant = "true>" if prefetch else "false>"      # focal_stream_kernel<U, logits, carries assignment>
     if os.path.exists(tfile):
         rec = json.load(open(tfile))
         if rec.get("source_sha256") == kernel_source_hash():
-            traffic, traffic_note = rec.get("hbm_bytes_per_launch"), rec.get("how", "rocprofv3 PMC")
+            for name, k in rec.get("kernels", {}).items():
+                if name.endswith(variant) and ", false, " in name:
+                    traffic, traffic_note = k["hbm_bytes_per_launch"], rec.get("how", "rocprofv3 PMC")
         else:
             traffic_note = "PMC summary is of other kernel sources: not reported"
 
@@ -466,16 +480,22 @@ def main():
                    "global_batch": BATCH * world, "parallelism": f"dp{world}", "launch": launch,
                    "eager_ms_per_step": eager_ms},
         "parity_ok": parity,
-        "roofline": {"bound": "hbm", "kernel": "focal_stream_kernel", "achieved": achieved,
+        "roofline": {"bound": "hbm",
+                     "kernel": "focal_stream_kernel<5, false, %s>" % ("true" if prefetch else "false")
+                               + (" (the [B,N,C] stream; its grid ends with the next step's assignment"
+                                  " workgroups, whose bytes are not counted)" if prefetch else ""),
+                     "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_note,
                      "algorithmic_bytes": algo_bytes,
                      "kernel_ms_mean": k_mean, "kernel_ms_min": k_min,
                      "kernel_ms_p10_p50_p90": [k_p10, k_p50, k_p90],
                      "timing": "HIP events around trains of 20 back-to-back launches, 10 trains",
+                     "stream_alone_kernel_ms_mean": plain_mean,
+                     "stream_alone_frac": algo_bytes / (plain_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "single_launch_event_pair_ms_mean": k1_mean,
                      "single_launch_event_pair_ms_min": k1_min},
-        "kernels_ms": {"assign_stage": a_mean, "stream_stage": k_mean, "fused_call": f_mean,
+        "kernels_ms": {"assign_stage": a_mean, "stream_stage": plain_mean, "stream_stage_carrying_next_assignment": k_mean if prefetch else None, "fused_call": f_mean,
                        "stream_stage_from_logits": lg_mean,
                        "stream_stage_head_layout_from_logits": lv_mean},
         "decode_nms": {"images_per_s": BATCH / (piped_ms * 1e-3), "ms_per_batch": piped_ms,
