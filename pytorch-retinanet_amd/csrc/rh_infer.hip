@@ -870,17 +870,22 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(
 // The owner then decodes the box and writes (key, box, label) at its rank.
 // ---------------------------------------------------------------------------
 constexpr int kRankMax = 8192;   // 12 bytes of LDS per key: 96 KiB of the CU's 160
-constexpr int kRankKeys = 64;
+#ifndef RH_RANK_KPL
+#define RH_RANK_KPL 2
+#endif
+constexpr int kRankKpl = RH_RANK_KPL;       // keys per lane: clusters of 64 list entries per block
+constexpr int kRankKeys = 64 * kRankKpl;
 constexpr int kRankThreads = 512;
 constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankBatch = 3;   // groups of 64 tiles whose lists a wave loads together
 constexpr int kRankSlots = 4;   // list slots per tile loaded together
 
-// mode 0: score >= mine, 1: score > mine, 2: full (score, index) key > mine
+// mode 0: score >= mine, 1: score > mine, 2: full (score, index) key > mine; every list entry
+// read is compared with the lane's kRankKpl keys
 template <int kMode>
-__device__ __forceinline__ int rank_count(const unsigned* s_sk, const unsigned* s_ix, int qa,
-                                          const int qb, const unsigned mys, const unsigned myx) {
-  int rank = 0;
+__device__ __forceinline__ void rank_count(const unsigned* s_sk, const unsigned* s_ix, int qa,
+                                           const int qb, const unsigned (&mys)[kRankKpl],
+                                           const unsigned (&myx)[kRankKpl], int (&rank)[kRankKpl]) {
   // eight entries per round as 16-byte LDS reads (uniform address: broadcast).  Every caller's
   // qa is a multiple of 8 whenever the range is not empty.
   for (; qa + 8 <= qb; qa += 8) {
@@ -897,18 +902,23 @@ __device__ __forceinline__ int rank_count(const unsigned* s_sk, const unsigned* 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const unsigned sk = sk8[u];
-      if (kMode == 0) rank += sk >= mys;
-      if (kMode == 1) rank += sk > mys;
-      if (kMode == 2) rank += (((u64)sk << 32) | ix8[u]) > (((u64)mys << 32) | myx);
+#pragma unroll
+      for (int c = 0; c < kRankKpl; ++c) {
+        if (kMode == 0) rank[c] += sk >= mys[c];
+        if (kMode == 1) rank[c] += sk > mys[c];
+        if (kMode == 2) rank[c] += (((u64)sk << 32) | ix8[u]) > (((u64)mys[c] << 32) | myx[c]);
+      }
     }
   }
   for (; qa < qb; ++qa) {
     const unsigned sk = s_sk[qa];
-    if (kMode == 0) rank += sk >= mys;
-    if (kMode == 1) rank += sk > mys;
-    if (kMode == 2) rank += (((u64)sk << 32) | s_ix[qa]) > (((u64)mys << 32) | myx);
+#pragma unroll
+    for (int c = 0; c < kRankKpl; ++c) {
+      if (kMode == 0) rank[c] += sk >= mys[c];
+      if (kMode == 1) rank[c] += sk > mys[c];
+      if (kMode == 2) rank[c] += (((u64)sk << 32) | s_ix[qa]) > (((u64)mys[c] << 32) | myx[c]);
+    }
   }
-  return rank;
 }
 
 __host__ __device__ inline int rank_lds_keys(int cap) { return (cap + 63) & ~63; }
@@ -1066,40 +1076,57 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   RH_TL(0, 2);
   const int K = min(found, cap);
   const int ke = topk > 0 ? min(K, topk) : K;
-  const int p = p0 + lane;
-  const int pc = min(p, max(K - 1, 0));
-  const unsigned mys = s_sk[pc], myx = s_ix[pc];
+  // lane l counts for list entries p0 + c*64 + l, c < kRankKpl: one pass over the list serves
+  // them all
+  unsigned mys[kRankKpl], myx[kRankKpl];
+  int rank[kRankKpl];
+#pragma unroll
+  for (int c = 0; c < kRankKpl; ++c) {
+    const int pc = min(p0 + c * 64 + lane, max(K - 1, 0));
+    mys[c] = s_sk[pc];
+    myx[c] = s_ix[pc];
+    rank[c] = 0;
+  }
   // wave w counts in [q0, q1): equal shares of the list, multiples of 8 entries
   const int seg = ((K + 8 * kRankWaves - 1) / (8 * kRankWaves)) << 3;
   const int q0 = min(wave * seg, K), q1 = min(q0 + seg, K);
-  int rank;
   if (src.from_tiles && (src.tiles_per_image > 0 || src.list_key)) {
-    rank = rank_count<2>(s_sk, s_ix, q0, q1, mys, myx);      // list not in anchor order: full keys
+    rank_count<2>(s_sk, s_ix, q0, q1, mys, myx, rank);      // list not in anchor order: full keys
   } else {
-    rank = rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx);
-    rank += rank_count<2>(s_sk, s_ix, max(q0, p0), min(q1, p0 + kRankKeys), mys, myx);
-    rank += rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx);
+    rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx, rank);
+    rank_count<2>(s_sk, s_ix, max(q0, p0), min(q1, p0 + kRankKeys), mys, myx, rank);
+    rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx, rank);
   }
-  s_part[wave][lane] = rank;
-  // The pair kernel ORs bits into the predecessor words: zero the words of the 64 ranks
-  // [p0, p0 + 64) (whichever keys end up there), words 0 .. p0/64, one 512-byte row per store.
-  if (p < ke)
-    for (int w = wave; w <= (int)blockIdx.y; w += kRankWaves)
-      so.mask[((size_t)j * so.wstride + w) * so.box_stride + p] = 0ull;
+#pragma unroll
+  for (int c = 0; c < kRankKpl; ++c) s_part[wave][c * 64 + lane] = rank[c];
+  // The pair kernel ORs bits into the predecessor words: zero the words of the ranks
+  // [p0, p0 + kRankKeys) (whichever keys end up there), for rank r the words 0 .. r/64, one
+  // 512-byte row per store.
+#pragma unroll
+  for (int c = 0; c < kRankKpl; ++c) {
+    const int r = p0 + c * 64 + lane;
+    if (r < ke)
+      for (int w = wave; w <= (int)blockIdx.y * kRankKpl + c; w += kRankWaves)
+        so.mask[((size_t)j * so.wstride + w) * so.box_stride + r] = 0ull;
+  }
   __syncthreads();
   RH_TL(0, 3);
-  if (wave == 0) {
-    rank = 0;
+  if (wave < kRankKpl) {            // wave c finishes cluster c of the block
+    const int cluster = (int)blockIdx.y * kRankKpl + wave;
+    const int p = p0 + wave * 64 + lane;
+    const int pc = min(p, max(K - 1, 0));
+    const unsigned ms = s_sk[pc], mx = s_ix[pc];
+    int rk = 0;
 #pragma unroll
-    for (int w = 0; w < kRankWaves; ++w) rank += s_part[w][lane];
-    const bool passed = p < K && rank < ke;      // else beyond the list, or cut by the top-k
+    for (int w = 0; w < kRankWaves; ++w) rk += s_part[w][wave * 64 + lane];
+    const bool passed = p < K && rk < ke;      // else beyond the list, or cut by the top-k
     float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p < K) {
       const size_t q = (size_t)j * so.list_stride + p;
       if (passed) {
-        const size_t o = (size_t)j * so.box_stride + rank;
-        so.keys[(size_t)j * so.key_stride + rank] = ((u64)mys << 32) | (u64)myx;
-        const unsigned idx = 0xFFFFFFFFu - myx;
+        const size_t o = (size_t)j * so.box_stride + rk;
+        so.keys[(size_t)j * so.key_stride + rk] = ((u64)ms << 32) | (u64)mx;
+        const unsigned idx = 0xFFFFFFFFu - mx;
         if (src.from_tiles) {
           const unsigned n = idx - (unsigned)j * (unsigned)src.N;
           box = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
@@ -1112,17 +1139,19 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
         so.slabel[o] = s_lab[p];
         for (int g = 0; g < so.nzw; ++g) so.nz[o * so.nzw + g] = 0ull;
       }
-      so.cinfo[q] = make_int4(passed ? rank : -1, s_lab[p],
+      so.cinfo[q] = make_int4(passed ? rk : -1, s_lab[p],
                               __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
     }
-    // this block's 64 list entries are one cluster of the pair kernel
-    const ClusterSummary cs = summarize_cluster(box, passed);
-    if (lane == 0) {
-      float4* out = so.csum + ((size_t)j * so.clusters + blockIdx.y) * 2;
-      out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
-      out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
+    // each 64 list entries are one cluster of the pair kernel
+    if (cluster < so.clusters) {
+      const ClusterSummary cs = summarize_cluster(box, passed);
+      if (lane == 0) {
+        float4* out = so.csum + ((size_t)j * so.clusters + cluster) * 2;
+        out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
+        out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
+      }
     }
-    if (blockIdx.y == 0 && lane == 0) {
+    if (blockIdx.y == 0 && wave == 0 && lane == 0) {
       if (!src.list_key) {           // (the selection kernel has written these two)
         counters[j] = found;
         counters[batch + j] = max(found - cap, 0);
