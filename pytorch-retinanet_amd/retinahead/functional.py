@@ -701,6 +701,21 @@ def nms_static(boxes, scores, iou_threshold, keep, count, labels=None):
     return keep, count
 
 
+# Largest post-processing workspace a call may ask for.  The NMS keeps a predecessor bitmap of
+# boxes x boxes / 8 bytes per image, so tens of thousands of boxes per image reaching the NMS
+# (no pre_nms_topk, a low score threshold on an untrained model) would need gigabytes.
+MAX_POST_WORKSPACE_BYTES = 2 << 30
+
+
+def _check_post_workspace(need, bsz, box_cap):
+    if need > MAX_POST_WORKSPACE_BYTES:
+        raise RetinaHeadError(
+            f"post-processing would need {need / 2**30:.1f} GiB of workspace: up to {box_cap} boxes per "
+            f"image reach the NMS, whose bitmap grows with the square of that ({bsz} images).  Pass "
+            f"pre_nms_topk (a few thousand loses nothing in practice) or raise the score threshold; "
+            f"retinahead.functional.MAX_POST_WORKSPACE_BYTES lifts the limit")
+
+
 def postprocess_raw(classifications, regressions, anchors_t, height, width, score_thresh=0.05,
                     iou_thresh=0.5, per_class=False, pre_nms_topk=0, max_det=0, cand_cap=4096,
                     stages=_lib.POST_ALL, out=None, from_logits=False, ws=None):
@@ -737,6 +752,7 @@ def postprocess_raw(classifications, regressions, anchors_t, height, width, scor
     need = lib.rh_postprocess_workspace_bytes(bsz, n, c, C.byref(params))
     if need == 0:
         raise RetinaHeadError("postprocess: " + _lib.last_error())
+    _check_post_workspace(need, bsz, box_cap)
     out["workspace_bytes"] = int(need)
     if ws is None:
         ws = workspace(dev, need, "post")
@@ -807,6 +823,7 @@ def postprocess_levels_raw(cls_levels, reg_levels, anchors_t, height, width, sco
     need = lib.rh_postprocess_levels_workspace_bytes(bsz, nl, h_arr, w_arr, a, c, C.byref(params))
     if need == 0:
         raise RetinaHeadError("postprocess_levels: " + _lib.last_error())
+    _check_post_workspace(need, bsz, box_cap)
     ws = workspace(dev, need, "post_levels")
     cnt = out["counts"]
     with torch.cuda.device(dev):

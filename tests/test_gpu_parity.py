@@ -1035,6 +1035,17 @@ def test_postprocess_topk_preselection(rh):
     assert int(over.min()) > 3 * 4096 - 100 and int(raw["counts"][2].max()) == 0
 
 
+def test_postprocess_workspace_is_bounded(rh, monkeypatch):
+    """Every anchor over the threshold and no pre_nms_topk: the retry would size the NMS bitmap for
+    all of them; past the limit the call refuses with advice instead of allocating."""
+    cls, reg, anc = infer_batch(12, 2, 256, 4, mu=0.0)
+    monkeypatch.setattr(rh.functional, "MAX_POST_WORKSPACE_BYTES", 8 << 20)
+    with pytest.raises(rh.RetinaHeadError, match="pre_nms_topk"):
+        rh.postprocess(dev(cls), dev(reg), dev(anc), (256, 256))
+    res = rh.postprocess(dev(cls), dev(reg), dev(anc), (256, 256), pre_nms_topk=500)
+    assert all(0 < r["scores"].numel() <= 500 for r in res)
+
+
 def test_postprocess_overflow_retry_and_odd_classes(rh):
     cls, reg, anc = infer_batch(3, 2, 128, 601, mu=-7.0)
     check_post(rh, cls, reg, anc, 128, max_candidates=64)      # forces the exact second pass
