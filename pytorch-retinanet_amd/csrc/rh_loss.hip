@@ -122,6 +122,13 @@ __device__ long long rh_dbg[8 * 65536];
 #else
 #define RH_MARK(slot)
 #endif
+// Epochs tag the partial records of one loss call (see StreamFinal): odd, and mixed with the
+// clock so that a workspace whose epoch word was overwritten (the buffer served another shape in
+// between, or is fresh and zero like the last fresh one) does not walk the same sequence again.
+__device__ __forceinline__ unsigned next_epoch(const unsigned e) {
+  return ((e ^ (unsigned)wall_clock64()) * 1664525u + 1013904223u) | 1u;
+}
+
 // Everything the assignment of one batch reads and writes.
 struct AssignArgs {
   const float4* anchors;
@@ -135,6 +142,7 @@ struct AssignArgs {
   int* label;
   float* iou_max;
   int* blk_pos;
+  unsigned* epoch;   // of the loss call that follows (null: none): advanced here
   int N, M, C;
   float neg_thresh, pos_thresh;
   CodeLayout lay;
@@ -371,6 +379,7 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
     if (lane == 0) {
       gt_count[j] = cnt;
       if (status) status[j] = bits;
+      if (aa.epoch && j == 0) *aa.epoch = next_epoch(*aa.epoch);   // the loss call that follows starts a new epoch
     }
   }
   RH_MARK(3);
@@ -563,6 +572,280 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 }
 
 // ---------------------------------------------------------------------------
+// Final reduction: fixed order, double accumulation.  One WAVE sums the partial records of one
+// image (lane-strided, then a butterfly), applies the normalisers of losses.py:94 and :134 and
+// writes the image's outputs; the batch means of losses.py:139-141 are then formed from the
+// images in ascending order.  Two callers share this code, so their results are the same bits:
+// finalize_kernel (one workgroup, wave w takes images w, w+16, ...) and the last workgroup of
+// the tile stream kernel to finish an image (below).
+// tile_mode > 0: partials are the tile kernel's records, tile_mode x 32 bytes per tile (four
+// (value, tag) atoms, below); 0: the row / level kernels' [B][blocks][2].
+// kCoherent: the records are being written during the SAME launch by other workgroups, as
+// device-scope atomic stores; they are read as device-scope atomic loads, again and again until
+// each carries the call's tag.
+// ---------------------------------------------------------------------------
+constexpr int kFinalBatch = 9;
+constexpr int kFinishSpins = 1 << 21;   // about two seconds of polling before giving up
+struct ImageLoss {
+  float cl, rl;
+  int pos;
+};
+struct FinalIn {
+  const float* partials;
+  const int* blk_pos;
+  int nblk;
+  const int* gt_count;
+  float* per_image;
+  int* num_pos_out;
+  int B, N, tile_mode, generic_blocks;
+  const float* pos_total;
+  unsigned tag;    // kCoherent readers: the tag this call's records carry
+};
+
+// A tile record is four 8-byte atoms, (value, tag): classification and regression sums of the
+// tile's first image, then of its second.  An atom is written by one aligned 64-bit store, so a
+// reader sees it whole.
+__device__ __forceinline__ unsigned long long make_atom(const float v, const unsigned tag) {
+  return (unsigned long long)__float_as_uint(v) | ((unsigned long long)tag << 32);
+}
+__device__ __forceinline__ unsigned long long load_atom_coherent(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_atom_coherent(unsigned long long* p, const unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All 64 lanes of one wave; every lane returns the image's results.  kBatch: records requested
+// together per lane (18 for the polling reader, one round for an image of 1084 tiles, would not
+// fit the stream kernel's 96 registers: 256 bytes of spill and a slower kernel for everyone).
+template <bool kCoherent, int kBatch>
+__device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int j) {
+  const int lane = threadIdx.x & 63;
+  const int nblk = f.nblk, N = f.N, tile_mode = f.tile_mode;
+  double c = 0.0, r = 0.0;
+  bool timed_out = false;
+  // the small loads go out with the first batch of records, not after the last
+  int npv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) npv[k] = f.blk_pos[(size_t)j * nblk + min(lane + k * 64, nblk - 1)];
+  const int gtc = f.gt_count[j];
+  const float total = f.pos_total ? *f.pos_total : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  if (tile_mode) {
+    const long long first = (long long)j * N, last = first + N - 1;
+    const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
+    // only the image's first tile can also hold rows of the previous image; there this
+    // image is the tile's second one
+    const bool shared_first = (first % kTileRows) != 0;
+    const int u_shared = (t_lo + 1) * tile_mode;      // records below it belong to tile t_lo
+    // (kBatch loads in flight per lane, only the half of each record that belongs to
+    // this image, and the small loads above issued with them: 6.0 -> 5.4 us for the kernel at
+    // 1084 tiles per image.  Twice the batch changes nothing.)
+    const int u_end = (t_hi + 1) * tile_mode;
+    const unsigned long long* atoms = reinterpret_cast<const unsigned long long*>(f.partials);
+#pragma nounroll
+    for (int u0 = t_lo * tile_mode + lane; u0 < u_end; u0 += 64 * kBatch) {
+      unsigned long long qc[kBatch], qr[kBatch];   // this image's two atoms of each record
+      for (int spin = 0;; ++spin) {
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+          const int u = min(u0 + k * 64, u_end - 1);
+          const size_t at = 4 * (size_t)u + 2 * (shared_first && u < u_shared);
+          if (kCoherent) {
+            qc[k] = load_atom_coherent(atoms + at);
+            qr[k] = load_atom_coherent(atoms + at + 1);
+          } else {
+            qc[k] = atoms[at];
+            qr[k] = atoms[at + 1];
+          }
+        }
+        if (!kCoherent) break;
+        // written during this launch: wait until every atom carries the call's tag
+        bool all_in = true;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+          all_in &= (unsigned)(qc[k] >> 32) == f.tag && (unsigned)(qr[k] >> 32) == f.tag;
+        if (__ballot(!all_in) == 0ull) break;
+        if (spin >= kFinishSpins) {          // (a logic error: report it, do not hang)
+          timed_out = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        if (u0 + k * 64 < u_end) {
+          c += __uint_as_float((unsigned)qc[k]);
+          r += __uint_as_float((unsigned)qr[k]);
+          if (kCoherent) {      // consumed: tag 0 again, which no call expects
+            const int u = u0 + k * 64;
+            const size_t at = 4 * (size_t)u + 2 * (shared_first && u < u_shared);
+            unsigned long long* w = const_cast<unsigned long long*>(atoms);
+            store_atom_coherent(w + at, qc[k] & 0xFFFFFFFFull);
+            store_atom_coherent(w + at + 1, qr[k] & 0xFFFFFFFFull);
+          }
+        }
+      }
+    }
+  } else {
+    // (unrolled: the loads of eight rounds go out together instead of one latency each)
+    const float2* pj = reinterpret_cast<const float2*>(f.partials) + (size_t)j * f.generic_blocks;
+#pragma unroll 8
+    for (int t = lane; t < f.generic_blocks; t += 64) {
+      const float2 q = pj[t];
+      c += q.x;
+      r += q.y;
+    }
+  }
+  int np = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) np += lane + k * 64 < nblk ? npv[k] : 0;
+  for (int i = lane + 256; i < nblk; i += 64) np += f.blk_pos[(size_t)j * nblk + i];
+  const bool empty = gtc == 0;
+  c = wave_sum(c);
+  r = wave_sum(r);
+  np = wave_sum(np);
+  // batch-wide normaliser: every image is divided by the one total (an image's share of
+  // the batch loss); otherwise by its own count, losses.py:94 and :134
+  const float npf = f.pos_total ? total : (float)np;
+  ImageLoss out;
+  out.cl = empty ? 0.f : (float)c / fmaxf(npf, 1.f);
+  out.rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * npf);
+  out.pos = np;
+  if (timed_out) out.cl = out.rl = __builtin_nanf("");
+  if (lane == 0) {
+    if (f.per_image) {
+      f.per_image[j] = out.cl;
+      f.per_image[f.B + j] = out.rl;
+    }
+    if (f.num_pos_out) f.num_pos_out[j] = np;
+  }
+  return out;
+}
+
+// One thread: the call's five output floats from the batch sums.
+__device__ __forceinline__ void store_batch_losses(float* losses, const double bc, const double br,
+                                                   const long long bp, const int B,
+                                                   const float divisor) {
+  const float lc = (float)(bc / (double)divisor), lr = (float)(br / (double)divisor);
+  losses[0] = lc;
+  losses[1] = lr;
+  // what data-parallel ranks exchange beside the two losses, ready in the same 16 bytes
+  losses[2] = (float)bp;
+  losses[3] = (float)B;
+  losses[4] = lc + lr;   // what train.py:185 forms from the two; saves the caller two launches
+}
+
+constexpr int kFinalThreads = 1024;
+
+__global__ __launch_bounds__(kFinalThreads) void finalize_kernel(const FinalIn f, float* __restrict__ losses,
+                                                                float divisor) {
+  __shared__ float s_img[2][kFinalThreads / 64];
+  __shared__ int s_pos[kFinalThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double bc = 0.0, br = 0.0;     // thread 0 only: batch sums, images visited in ascending order
+  long long bp = 0;              // positives of the whole call
+  for (int j0 = 0; j0 < f.B; j0 += kFinalThreads / 64) {
+    const int j = j0 + wave;
+    ImageLoss il{0.f, 0.f, 0};
+    if (j < f.B) il = finalize_image<false, kFinalBatch>(f, j);
+    __syncthreads();
+    if (lane == 0) {
+      s_img[0][wave] = il.cl;
+      s_img[1][wave] = il.rl;
+      s_pos[wave] = il.pos;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 0; w < kFinalThreads / 64; ++w) {
+        bc += s_img[0][w];
+        br += s_img[1][w];
+        bp += s_pos[w];
+      }
+    }
+  }
+  if (threadIdx.x == 0) store_batch_losses(losses, bc, br, bp, f.B, divisor);
+}
+
+// The same inside the tile stream kernel, when the call runs both stages: one finishing
+// workgroup per image sits at the end of the stream's part of the grid, polls the image's records
+// until they are all in, and reduces them; the one that completes the call's last image forms the
+// batch means.  No launch, kernel boundary or trip through memory is left after the stream, and
+// with the next step's assignment riding behind, the last image's reduction hides under it.
+// Writers never wait: a record atom is (value, tag) in one aligned 64-bit device-scope store,
+// the tag being the workspace's EPOCH, an odd number that the assignment stage and the end of
+// every such call advance (mixed with the clock), so records of earlier calls -- or whatever a
+// fresh workspace holds -- do not look finished; a stream stage run on its own writes tag 0, and
+// a finisher puts tag 0 back on every atom it has consumed.  Ordering a ticket after
+// the record instead (store, wait for the acknowledgement, atomic add) was measured: the wait
+// also covers the wave's streamed gradient stores and doubled the kernel's time; a release
+// fence, whose L2 write-back sits behind 370 MB of such stores, took it from 0.12 to 0.95 ms.
+struct StreamFinal {
+  int enabled;
+  unsigned* epoch;   // [1] the workspace's epoch
+  float* img_out;    // [B] x three atoms: classification loss, regression loss, positives
+  float* losses;
+  float divisor;
+  FinalIn in;
+};
+
+// One wave: reduces image j as its records arrive and publishes the image's results the same
+// way, as three tagged atoms; the finisher of image 0 then collects all images (polling, like
+// the records) and forms the batch means.
+__device__ __forceinline__ void stream_finish_image(const StreamFinal& fin, const int j) {
+  const int lane = threadIdx.x & 63;
+  FinalIn in = fin.in;
+  const unsigned tag = *fin.epoch;
+  in.tag = tag;
+  const ImageLoss il = finalize_image<true, kFinalBatch>(in, j);
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(fin.img_out);
+  if (lane == 0) {
+    store_atom_coherent(out + 3 * (size_t)j, make_atom(il.cl, tag));
+    store_atom_coherent(out + 3 * (size_t)j + 1, make_atom(il.rl, tag));
+    store_atom_coherent(out + 3 * (size_t)j + 2, make_atom(__int_as_float(il.pos), tag));
+  }
+  if (j != 0) return;
+  // the batch means, images in ascending order (as finalize_kernel sums them)
+  double bc = 0.0, br = 0.0;
+  long long bp = 0;
+  bool timed_out = false;
+  for (int i0 = 0; i0 < in.B; i0 += 64) {
+    const int i = min(i0 + lane, in.B - 1);
+    unsigned long long a0, a1, a2;
+    for (int spin = 0;; ++spin) {
+      a0 = load_atom_coherent(out + 3 * (size_t)i);
+      a1 = load_atom_coherent(out + 3 * (size_t)i + 1);
+      a2 = load_atom_coherent(out + 3 * (size_t)i + 2);
+      const bool in_ = (unsigned)(a0 >> 32) == tag && (unsigned)(a1 >> 32) == tag &&
+                       (unsigned)(a2 >> 32) == tag;
+      if (__ballot(!in_) == 0ull) break;
+      if (spin >= kFinishSpins) {
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (i0 + lane < in.B) {       // consumed
+      store_atom_coherent(out + 3 * (size_t)i, a0 & 0xFFFFFFFFull);
+      store_atom_coherent(out + 3 * (size_t)i + 1, a1 & 0xFFFFFFFFull);
+      store_atom_coherent(out + 3 * (size_t)i + 2, a2 & 0xFFFFFFFFull);
+    }
+    const int cnt = min(64, in.B - i0);
+    for (int w = 0; w < cnt; ++w) {
+      bc += (double)__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)a0, w));
+      br += (double)__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)a1, w));
+      bp += __builtin_amdgcn_readlane((int)(unsigned)a2, w);
+    }
+  }
+  if (lane == 0) {
+    *fin.epoch = next_epoch(tag);        // this call's records are history now
+    if (timed_out) bc = br = (double)__builtin_nanf("");
+    store_batch_losses(fin.losses, bc, br, bp, in.B, fin.divisor);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Tile stream kernel.  The [B*N, C] probability matrix is cut into tiles of 64
 // consecutive rows; a tile starts at a multiple of 64*C floats, so it is 16-byte
 // aligned for every C and is read / written as float4 regardless of row length.
@@ -593,7 +876,6 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // the end of the grid 137.2 us.)
 struct AheadArgs {
   AssignArgs aa;
-  int first;    // first assignment workgroup = number of stream workgroups
   int batch;
   int nblk;
 };
@@ -605,16 +887,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     const int* __restrict__ code, const int* __restrict__ blk_pos, int nblk,
     float* __restrict__ partials, int N, int C, int M, int total_rows, int num_tiles,
     unsigned magic_c, FocalConst fc, float gcls, float greg, float divisor,
-    const float* __restrict__ pos_total, int parts, int part_vecs, const AheadArgs ahead) {
-  int unit_stride = gridDim.x;
-  if (kAhead) {
-    const int at = (int)blockIdx.x - ahead.first;
-    if (at >= 0) {
-      const int b = at / ahead.batch;
-      assign_block<false>(ahead.aa, at - b * ahead.batch, ahead.nblk - 1 - b, ahead.nblk);
+    const float* __restrict__ pos_total, int parts, int part_vecs, const AheadArgs ahead,
+    const StreamFinal fin) {
+  // Grid: the stream's workgroups, then (both stages in one call) one finishing workgroup per
+  // image, then (kAhead) the next step's assignment.
+  const int units = num_tiles * parts;
+  if ((int)blockIdx.x >= units) {
+    const int extra = (int)blockIdx.x - units;
+    const int finishers = fin.enabled ? fin.in.B : 0;
+    if (extra < finishers) {
+      if (threadIdx.x < 64) stream_finish_image(fin, extra);
       return;
     }
-    unit_stride = ahead.first;
+    if (kAhead) {
+      const int at = extra - finishers;
+      const int b = at / ahead.batch;
+      assign_block<false>(ahead.aa, at - b * ahead.batch, ahead.nblk - 1 - b, ahead.nblk);
+    }
+    return;
   }
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
@@ -628,7 +918,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
   // workgroup streams about as much as it does at C = 80 -- short-lived workgroups whose loads
   // all go out at once, and enough of them to fill the chip evenly.  Part 0 also does the
   // tile's regression rows.
-  for (int unit = blockIdx.x; unit < num_tiles * parts; unit += unit_stride) {
+  for (int unit = blockIdx.x; unit < units; unit += units) {
     const int tile = parts == 1 ? unit : unit / parts;
     const int part = unit - tile * parts;
     const int row0 = tile * kTileRows;
@@ -808,9 +1098,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     if (tid == 0) {
       const float4 a = s_red[0], b = s_red[1], c = s_red[2], d = s_red[3];
       // record: (classification, regression) of the tile's first image, then of its second
-      reinterpret_cast<float4*>(partials)[unit] =
-          make_float4((a.x + b.x) + (c.x + d.x), (a.z + b.z) + (c.z + d.z),
-                      (a.y + b.y) + (c.y + d.y), (a.w + b.w) + (c.w + d.w));
+      const float4 rec = make_float4((a.x + b.x) + (c.x + d.x), (a.z + b.z) + (c.z + d.z),
+                                     (a.y + b.y) + (c.y + d.y), (a.w + b.w) + (c.w + d.w));
+      // four (value, tag) atoms; tag 0 (never an epoch) when the reduction is a later launch
+      unsigned long long* atoms = reinterpret_cast<unsigned long long*>(partials) + 4 * (size_t)unit;
+      if (!fin.enabled) {
+        atoms[0] = make_atom(rec.x, 0u);
+        atoms[1] = make_atom(rec.y, 0u);
+        atoms[2] = make_atom(rec.z, 0u);
+        atoms[3] = make_atom(rec.w, 0u);
+      } else {
+        const unsigned tag = *fin.epoch;
+        store_atom_coherent(atoms + 0, make_atom(rec.x, tag));
+        store_atom_coherent(atoms + 1, make_atom(rec.y, tag));
+        store_atom_coherent(atoms + 2, make_atom(rec.z, tag));
+        store_atom_coherent(atoms + 3, make_atom(rec.w, tag));
+      }
     }
   }
 }
@@ -1086,126 +1389,6 @@ __global__ __launch_bounds__(kLvlThreads) void focal_levels_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// Final reduction, one workgroup of 16 waves, fixed order, double accumulation.
-// Wave w sums the partials of images w, w+16, ... (lane-strided, then a butterfly)
-// and applies the normalisers of losses.py:94 and :134; wave 0 then forms the batch
-// means of losses.py:139-141.  tile_mode > 0: partials are the tile kernel's records,
-// tile_mode float4 per tile; 0: the row / level kernels' [B][blocks][2].
-// ---------------------------------------------------------------------------
-constexpr int kFinalThreads = 1024;
-constexpr int kFinalBatch = 9;
-
-__global__ __launch_bounds__(kFinalThreads) void finalize_kernel(
-    const float* __restrict__ partials, const int* __restrict__ blk_pos, int nblk,
-    const int* __restrict__ gt_count, float* __restrict__ per_image, int* __restrict__ num_pos_out,
-    float* __restrict__ losses, int B, int N, int tile_mode, int generic_blocks, float divisor,
-    const float* __restrict__ pos_total) {
-  __shared__ float s_img[2][kFinalThreads / 64];
-  __shared__ int s_pos[kFinalThreads / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double bc = 0.0, br = 0.0;     // wave 0 only: batch sums, images visited in ascending order
-  long long bp = 0;              // positives of the whole call
-  for (int j0 = 0; j0 < B; j0 += kFinalThreads / 64) {
-    const int j = j0 + wave;
-    float cl = 0.f, rl = 0.f;
-    int pos = 0;
-    if (j < B) {
-      double c = 0.0, r = 0.0;
-      // the small loads go out with the first batch of records, not after the last
-      int npv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) npv[k] = blk_pos[(size_t)j * nblk + min(lane + k * 64, nblk - 1)];
-      const int gtc = gt_count[j];
-      const float total = pos_total ? *pos_total : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-      if (tile_mode) {
-        const long long first = (long long)j * N, last = first + N - 1;
-        const int t_lo = (int)(first / kTileRows), t_hi = (int)(last / kTileRows);
-        // only the image's first tile can also hold rows of the previous image; there this
-        // image is the tile's second one
-        const bool shared_first = (first % kTileRows) != 0;
-        const int u_shared = (t_lo + 1) * tile_mode;      // records below it belong to tile t_lo
-        // (kFinalBatch loads in flight per lane, only the half of each record that belongs to
-        // this image, and the small loads above issued with them: 6.0 -> 5.4 us at 1084 tiles
-        // per image.  Twice the batch changes nothing: what remains is the launch, one trip to
-        // memory, the barriers and the final stores.)
-        const int u_end = (t_hi + 1) * tile_mode;
-#pragma nounroll
-        for (int u0 = t_lo * tile_mode + lane; u0 < u_end; u0 += 64 * kFinalBatch) {
-          float2 q[kFinalBatch];      // the half of each record that is this image's
-#pragma unroll
-          for (int k = 0; k < kFinalBatch; ++k) {
-            const int u = min(u0 + k * 64, u_end - 1);
-            q[k] = reinterpret_cast<const float2*>(partials)[2 * u + (shared_first && u < u_shared)];
-          }
-#pragma unroll
-          for (int k = 0; k < kFinalBatch; ++k) {
-            if (u0 + k * 64 < u_end) {
-              c += q[k].x;
-              r += q[k].y;
-            }
-          }
-        }
-      } else {
-        // (unrolled: the loads of eight rounds go out together instead of one latency each)
-        const float2* pj = reinterpret_cast<const float2*>(partials) + (size_t)j * generic_blocks;
-#pragma unroll 8
-        for (int t = lane; t < generic_blocks; t += 64) {
-          const float2 q = pj[t];
-          c += q.x;
-          r += q.y;
-        }
-      }
-      int np = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) np += lane + k * 64 < nblk ? npv[k] : 0;
-      for (int i = lane + 256; i < nblk; i += 64) np += blk_pos[(size_t)j * nblk + i];
-      const bool empty = gtc == 0;
-      c = wave_sum(c);
-      r = wave_sum(r);
-      np = wave_sum(np);
-      pos = np;
-      // batch-wide normaliser: every image is divided by the one total (an image's share of
-      // the batch loss); otherwise by its own count, losses.py:94 and :134
-      const float npf = pos_total ? total : (float)np;
-      cl = empty ? 0.f : (float)c / fmaxf(npf, 1.f);
-      rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * npf);
-      if (lane == 0) {
-        if (per_image) {
-          per_image[j] = cl;
-          per_image[B + j] = rl;
-        }
-        if (num_pos_out) num_pos_out[j] = np;
-      }
-    }
-    __syncthreads();
-    if (lane == 0) {
-      s_img[0][wave] = cl;
-      s_img[1][wave] = rl;
-      s_pos[wave] = pos;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int w = 0; w < kFinalThreads / 64; ++w) {
-        bc += s_img[0][w];
-        br += s_img[1][w];
-        bp += s_pos[w];
-      }
-    }
-  }
-  if (threadIdx.x == 0) {
-    const float lc = (float)(bc / (double)divisor), lr = (float)(br / (double)divisor);
-    losses[0] = lc;
-    losses[1] = lr;
-    // what data-parallel ranks exchange beside the two losses, ready in the same 16 bytes
-    losses[2] = (float)bp;
-    losses[3] = (float)B;
-    losses[4] = lc + lr;   // what train.py:185 forms from the two; saves the caller two launches
-  }
-}
-
 // x *= (*sx) / assumed and y *= (*sy) / assumed in one launch; each array is left alone
 // (no traffic) when its scale equals `assumed`.  A null scale pointer means "zero the array".
 __global__ __launch_bounds__(kThreads) void apply_upstream_kernel(
@@ -1240,6 +1423,8 @@ struct LossWorkspace {
   int* code;
   float* partials;
   float* pos_total;  // [1] positives of the whole call (batch-wide normaliser only)
+  unsigned* epoch;   // [1] tag of the records of the call in flight (in-launch final reduction)
+  float* img_out;    // [B][6] per-image results on their way to the batch means (three atoms)
   size_t bytes;
 };
 
@@ -1257,13 +1442,13 @@ static int tile_parts(int c) {
 
 static long long partial_floats(int batch, long long n, int c) {
   const long long tiles = ((long long)batch * n + kTileRows - 1) / kTileRows;
-  const long long a = tiles * 4 * tile_parts(c), b = (long long)batch * kGenericBlocks * 2;
+  const long long a = tiles * 8 * tile_parts(c), b = (long long)batch * kGenericBlocks * 2;
   return a > b ? a : b;
 }
 
 static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) {
   Carver cv(ws);
-  LossWorkspace w;
+  LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
   w.nblk = assign_blocks(n, m);
@@ -1271,6 +1456,8 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
   w.pos_total = cv.take<float>(1);
+  w.epoch = cv.take<unsigned>(1);
+  w.img_out = cv.take<float>((size_t)batch * 6);
   w.bytes = cv.off;
   return w;
 }
@@ -1302,6 +1489,7 @@ static AssignArgs assign_args(const float* anchors, const float* annotations, lo
   aa.label = label;
   aa.iou_max = iou_max;
   aa.blk_pos = w.blk_pos;
+  aa.epoch = w.epoch;
   aa.N = (int)n;
   aa.M = m;
   aa.C = c;
@@ -1369,7 +1557,7 @@ static int level_csplit(int c) {
 
 static LossWorkspace carve_levels(void* ws, int batch, long long n, int m, long long blocks) {
   Carver cv(ws);
-  LossWorkspace w;
+  LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
   w.nblk = assign_blocks(n, m);
@@ -1401,6 +1589,23 @@ static int resolve_normaliser(const rh_focal_params* p, int batch, const LossWor
     out->divisor = (float)(p->batch_divisor > 0 ? p->batch_divisor : batch);
   }
   return RH_OK;
+}
+
+static FinalIn final_in(const LossWorkspace& w, float* per_image, int* num_pos, int batch,
+                        long long n, int tile_mode, const Normaliser& nrm) {
+  FinalIn f;
+  f.partials = w.partials;
+  f.blk_pos = w.blk_pos;
+  f.nblk = w.nblk;
+  f.gt_count = w.gt_count;
+  f.per_image = per_image;
+  f.num_pos_out = num_pos;
+  f.B = batch;
+  f.N = (int)n;
+  f.tile_mode = tile_mode;
+  f.generic_blocks = kGenericBlocks;
+  f.pos_total = nrm.total;
+  return f;
 }
 
 static int launch_count(const LossWorkspace& w, int batch, int* num_pos, hipStream_t s) {
@@ -1544,7 +1749,7 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
     if (params->normalizer == RH_NORM_GLOBAL)
       if (int e = launch_count(w, batch, num_pos, s)) return e;
   }
-  bool next_assigned = false;
+  bool next_assigned = false, finalized = false;
   if (stages & RH_STAGE_STREAM) {
     if (tile) {
       // float4 slots per thread and part: pick the unroll that wastes the fewest
@@ -1559,6 +1764,18 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
       // non-temporal loads and stores (the data is touched once) were worth another 8 %.
       // The next step's assignment joins this launch in its plain form (short annotation lists);
       // otherwise it follows as a launch of its own below.
+      // Both stages in one call: the stream kernel's workgroups reduce each image as its last
+      // record arrives and no finalize launch follows.
+      StreamFinal fin{};
+      fin.in = final_in(w, per_image, num_pos, batch, n, parts, nrm);
+      if (stages & RH_STAGE_FINALIZE) {
+        fin.enabled = 1;
+        fin.epoch = w.epoch;
+        fin.img_out = w.img_out;
+        fin.losses = losses;
+        fin.divisor = divisor;
+        finalized = true;
+      }
       AheadArgs ahead{};
       int ahead_blocks = 0;
       const bool ride = next && !assign_split(next->m) &&
@@ -1569,7 +1786,6 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
                                nullptr, nullptr, next->status, CodeLayout{});
         ahead.batch = batch;
         ahead.nblk = wn.nblk;
-        ahead.first = num_tiles * parts;
         ahead_blocks = batch * wn.nblk;
         next_assigned = true;
       }
@@ -1578,12 +1794,13 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
                             : (ride ? focal_stream_kernel<4, true, true> : focal_stream_kernel<4, true, false>))
                       : (u5 ? (ride ? focal_stream_kernel<5, false, true> : focal_stream_kernel<5, false, false>)
                             : (ride ? focal_stream_kernel<4, false, true> : focal_stream_kernel<4, false, false>));
-      hipLaunchKernelGGL(kern, dim3(num_tiles * parts + ahead_blocks), dim3(kThreads), 0, s,
+      hipLaunchKernelGGL(kern, dim3(num_tiles * parts + (fin.enabled ? batch : 0) + ahead_blocks),
+                         dim3(kThreads), 0, s,
                          classifications, d_classifications, regressions, d_regressions,
                          reinterpret_cast<const float4*>(anchors), w.gt, w.code, w.blk_pos, w.nblk,
                          w.partials, (int)n, num_classes, m, total_rows, num_tiles,
                          div_magic((unsigned)num_classes), fc, params->grad_cls, params->grad_reg,
-                         divisor, nrm.total, parts, part_vecs, ahead);
+                         divisor, nrm.total, parts, part_vecs, ahead, fin);
       RH_CHECK_LAUNCH("focal_stream_kernel");
     } else {
       auto kern = params->from_logits ? focal_rows_kernel<true> : focal_rows_kernel<false>;
@@ -1594,10 +1811,10 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
       RH_CHECK_LAUNCH("focal_rows_kernel");
     }
   }
-  if (stages & RH_STAGE_FINALIZE) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
-                       w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)n,
-                       tile ? tile_parts(num_classes) : 0, kGenericBlocks, divisor, nrm.total);
+  if ((stages & RH_STAGE_FINALIZE) && !finalized) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s,
+                       final_in(w, per_image, num_pos, batch, n, tile ? tile_parts(num_classes) : 0, nrm),
+                       losses, divisor);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   if (next) {
@@ -1699,9 +1916,9 @@ int rh_focal_loss_levels_fwd_bwd(const float* const* cls_levels, const float* co
     RH_CHECK_LAUNCH("focal_levels_kernel");
   }
   if (stages & RH_STAGE_FINALIZE) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, w.partials, w.blk_pos,
-                       w.nblk, w.gt_count, per_image, num_pos, losses, batch, (int)lp.n, 0,
-                       (int)blocks, divisor, nrm.total);
+    FinalIn f = final_in(w, per_image, num_pos, batch, lp.n, 0, nrm);
+    f.generic_blocks = (int)blocks;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinalThreads), 0, s, f, losses, divisor);
     RH_CHECK_LAUNCH("finalize_kernel");
   }
   return RH_OK;

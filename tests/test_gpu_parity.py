@@ -403,6 +403,39 @@ def test_loss_sum_uses_the_stored_total(rh, focal_golden):
     assert torch.equal(reg.grad, grads[0][1])
 
 
+@pytest.mark.parametrize("bsz,size,c,m,valid,norm", [
+    (3, 256, 80, 8, [8, 0, 3], "per_image"),
+    (2, 160, 601, 6, [6, 2], "per_image"),       # tiles cut into parts: several records per tile
+    (70, 64, 8, 3, [3, 1, 0, 2], "per_image"),   # more images than a wave has lanes; N = 774, tiles straddle images
+    (5, 96, 20, 4, [4, 1], "global"),
+])
+def test_final_reduction_inside_the_stream_launch(rh, bsz, size, c, m, valid, norm):
+    """A call that runs the stream and the final reduction together reduces each image inside the
+    stream launch (finishing workgroups at the end of the grid, per-image tickets); run apart, the
+    stages use the finalize kernel.  Same code, same order: the same bits -- also on the second
+    call on a workspace (tickets back at zero) and against the oracle."""
+    F, L = rh.functional, rh._lib
+    cls, reg, anc, ann = make_batch(90 + c, bsz, size, c, m, valid)
+    d = [dev(x) for x in (cls, reg, anc, ann)]
+    apart = F.focal_loss_fwd_bwd(*d, stages=L.STAGE_ASSIGN, normalizer=norm)
+    F.focal_loss_fwd_bwd(*d, stages=L.STAGE_STREAM, out=apart, normalizer=norm)
+    F.focal_loss_fwd_bwd(*d, stages=L.STAGE_FINALIZE, out=apart, normalizer=norm)
+    for rep in range(3):
+        fused = F.focal_loss_fwd_bwd(*d, normalizer=norm)
+        torch.cuda.synchronize()
+        for k in ("losses", "exchange", "total", "per_image", "num_pos", "d_classifications", "d_regressions"):
+            assert torch.equal(fused[k], apart[k]), (k, rep)
+    assert torch.isfinite(fused["losses"]).all()
+    if norm == "per_image":
+        ref = O.focal_loss_fwd_bwd(cls, reg, anc, ann, grad_cls=1.0, grad_reg=1.0)
+        assert np.allclose(fused["losses"].cpu().numpy(),
+                           [ref["classification_loss"][0], ref["regression_loss"][0]], rtol=RTOL, atol=0)
+    # stream + finalize on a workspace whose assignment ran in an earlier call
+    late = F.focal_loss_fwd_bwd(*d, stages=L.STAGE_ASSIGN, normalizer=norm)
+    F.focal_loss_fwd_bwd(*d, stages=L.STAGE_STREAM | L.STAGE_FINALIZE, out=late, normalizer=norm)
+    assert torch.equal(late["losses"], apart["losses"]) and torch.equal(late["per_image"], apart["per_image"])
+
+
 def test_loss_deterministic_and_unaligned(rh):
     cls, reg, anc, ann = make_batch(3, 2, 128, 80, 5, [5, 2])
     a = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
