@@ -1907,6 +1907,9 @@ static NmsPlan make_plan(int batch, long long cap, int topk) {
   // worth its launch when at most half the room can pass (measured at 1024 px, 5600 candidates,
   // top-1000: the rank sort alone 36 us, selection + rank sort of the ~1100 kept 16 us)
   p.select = p.ranked && topk > 0 && 2ll * topk <= cap;
+  // (Not for every call: with nothing to cut, the selection's one workgroup per image is just a
+  // slower gather -- 608 px, 2000 candidates: 108 against 100 us alone, 74.6 against 69.7 us per
+  // batch with four in flight.)
   p.clusters = ((p.ranked ? p.cap : p.box_cap) + 63) / 64;
   return p;
 }
