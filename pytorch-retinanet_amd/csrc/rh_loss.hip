@@ -909,7 +909,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
   __shared__ int s_code[kTileRows];
   __shared__ float4 s_red[kThreads / 64];
   __shared__ int s_np[kThreads / 64][2];
+  __shared__ int s_special[2];
   const int tid = threadIdx.x;
+  if (tid == 0) s_special[0] = s_special[1] = 0;
+  int turn = 0;
   const float k0l = -(1.0f - fc.alpha) * kLn2;
   constexpr int UG = 2;   // unroll of the general (row-tracking) path: keeps registers low
 
@@ -947,8 +950,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     }
     const int my_code = tid < rows ? my_code_raw : kCodeNeg;
     if (tid < kTileRows) s_code[tid] = tid < rows ? my_code : kCodeIgn;
-    // any positive or ignored row in this tile?  (also the barrier that publishes s_code, s_np)
-    const int special = __syncthreads_or(my_code != kCodeNeg);
+    // any positive or ignored row in this tile?  An LDS flag and the barrier that publishes
+    // s_code and s_np anyway (the library's workgroup OR costs a reduction through LDS with
+    // barriers of its own); two flags take turns so that the next tile can clear its own.
+    if (__ballot(my_code != kCodeNeg) != 0ull && (tid & 63) == 0) s_special[turn] = 1;
+    __syncthreads();
+    const int special = s_special[turn];
+    turn ^= 1;
+    if (tid == 0) s_special[turn] = 0;
     const float np0 = pos_total ? total : (float)((s_np[0][0] + s_np[1][0]) + (s_np[2][0] + s_np[3][0]));
     const float np1 = pos_total ? total : (float)((s_np[0][1] + s_np[1][1]) + (s_np[2][1] + s_np[3][1]));
     const float norm0 = fmaxf(np0, 1.f), norm1 = fmaxf(np1, 1.f);
