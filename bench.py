@@ -466,6 +466,19 @@ def main():
     piped_ms = float(np.median(trial))
     trial_p10, trial_p90 = (float(np.percentile(trial, q)) for q in (10, 90))
     streams = stream_sets[int(np.argsort(trial)[len(trial) // 2])]
+    # the same through the public helper (its host read of the counts per batch included)
+    pipe = rh.PostprocessPipeline(depth=2 * n_streams, streams=n_streams)
+    def pipe_run(k):
+        for _ in range(k):
+            if len(pipe) == 2 * n_streams:
+                pipe.results()
+            pipe.submit(icls, ireg, anchors, (SIZE, SIZE))
+        while len(pipe):
+            pipe.results()
+    pipe_run(100)
+    t1 = time.perf_counter()
+    pipe_run(400)
+    pipe_ms = (time.perf_counter() - t1) / 400 * 1e3
     # the same with only equal labels suppressing each other (batched per-class NMS)
     per_class_ms = piped(lambda out=None: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, per_class=True,
                                                             cand_cap=4096, out=out), rounds=50)
@@ -528,7 +541,9 @@ def main():
                        "scan_stage_frac_of_hbm_peak": decode_bytes / (d_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "candidates_per_image": float(counts[1].mean()),
                        "kept_per_image": float(counts[0].mean()), "mode": "agnostic, thr 0.05, IoU 0.5",
-                       "per_class_images_per_s": BATCH / (per_class_ms * 1e-3)},
+                       "per_class_images_per_s": BATCH / (per_class_ms * 1e-3),
+                       "pipeline_class_ms_per_batch": pipe_ms,
+                       "pipeline_class_images_per_s": BATCH / (pipe_ms * 1e-3)},
     }
     line["cpu_baseline"] = None
     if not args.no_cpu_baseline and world == 1:      # the host-side baseline is timed at N=1 only

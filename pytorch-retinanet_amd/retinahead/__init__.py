@@ -8,9 +8,10 @@ from .modules import (Anchors, BBoxTransform, ClipBoxes, FocalLoss, GenericFocal
                       calc_iou, nms, postprocess)
 from .functional import collate_annotations, sigmoid
 from .evaluate import DetectionEvaluator
+from .pipeline import PostprocessPipeline
 from . import functional
 from . import dist
 
 __all__ = ["Anchors", "BBoxTransform", "ClipBoxes", "FocalLoss", "GenericFocalLoss", "batched_nms",
-           "calc_iou", "nms", "postprocess", "sigmoid", "collate_annotations", "DetectionEvaluator", "functional", "dist", "load_library", "LIB_PATH",
+           "calc_iou", "nms", "postprocess", "sigmoid", "collate_annotations", "DetectionEvaluator", "PostprocessPipeline", "functional", "dist", "load_library", "LIB_PATH",
            "RetinaHeadError"]
