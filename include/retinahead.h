@@ -174,7 +174,10 @@ void rh_focal_params_default(rh_focal_params* p);
  * can run it on a second stream, into a second workspace, while the current step's
  * RH_STAGE_STREAM is still running: the stream stage leaves the vector ALUs mostly idle.  The
  * caller orders the streams (the later stages of a step after its assignment stage; a
- * workspace's next assignment after the stages that still read it). */
+ * workspace's next assignment after the stages that still read it).
+ * RH_STAGE_STREAM | RH_STAGE_FINALIZE in one call reduce inside the stream launch (no further
+ * kernel); run apart they give the same bits.  Either way the workspace must have had its
+ * RH_STAGE_ASSIGN since it was allocated or last used for another shape. */
 enum rh_focal_stage {
   RH_STAGE_ASSIGN = 1,   /* GT compaction + IoU assignment + num_pos            */
   RH_STAGE_STREAM = 2,   /* N x C focal stream + smooth-L1, losses and gradients */
