@@ -295,6 +295,7 @@ template <bool kLogits>
 __global__ __launch_bounds__(kThreads) void score_scan_levels_kernel(LevelGeom lv, TileCands tc,
                                                                      int N, int C, float thresh,
                                                                      float pre) {
+  __builtin_amdgcn_s_setprio(3);      // as in score_scan_tile_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = blockIdx.y;
   int l = 0;
