@@ -142,3 +142,23 @@ def test_prefetch_in_two_alternating_graphs(rh):
         got = outs[i % 2]
         for k in range(4):
             assert torch.equal(got[k], want[k]), (i, k)
+
+
+def test_assignment_stage_on_its_own_stream(rh):
+    """functional.focal_assign: the assignment stage issued apart (here on a second stream, ordered
+    by events) into a workspace of its own; the remaining stages then give the plain call's bits."""
+    F, L = rh.functional, rh._lib
+    cls, reg, anc, ann = make_batch(80, 3, 160, 20, 6, [6, 0, 2])
+    d_cls, d_reg, d_anc, d_ann = dev(cls), dev(reg), dev(anc), dev(ann)
+    want = F.focal_loss_fwd_bwd(d_cls, d_reg, d_anc, d_ann)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out, ws = F.focal_assign(d_anc, d_ann, 20)
+    torch.cuda.current_stream().wait_stream(side)
+    got = F.focal_loss_fwd_bwd(d_cls, d_reg, d_anc, d_ann, stages=L.STAGE_STREAM | L.STAGE_FINALIZE,
+                               out=out, ws=ws)
+    for k in ("losses", "per_image", "num_pos", "status", "d_classifications", "d_regressions"):
+        assert torch.equal(got[k], want[k]), k
+    with pytest.raises(rh.RetinaHeadError):
+        F.focal_loss_fwd_bwd(d_cls, d_reg, d_anc, d_ann, ws=ws[:16])
