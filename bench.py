@@ -326,6 +326,38 @@ def main():
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t1) / 50 * 1e3
 
+    # the same step with every assignment in a launch of its own (no announcement of the next
+    # batch's annotations), replayed from one graph: what a loop that cannot look ahead gets
+    plain_ms = None
+    if graphs and prefetch:
+        try:
+            plain_mod = rh.FocalLoss(batch_divisor=BATCH * world)
+            def plain_step():
+                cls.grad = None
+                reg.grad = None
+                out = plain_mod(cls, reg, anchors, ann)
+                sum(l for l in out.values()).backward()
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    plain_step()
+            torch.cuda.synchronize()
+            cls.grad = None
+            reg.grad = None
+            pg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(pg, stream=side, capture_error_mode="thread_local"):
+                plain_step()
+            times = []
+            for _ in range(12):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    pg.replay()
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t1) / args.steps * 1e3)
+            plain_ms = float(np.median(times[2:]))
+        except Exception as e:                   # pragma: no cover - depends on the runtime
+            print(f"[bench] plain-step graph failed ({e!r})", file=sys.stderr)
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -505,7 +537,8 @@ def main():
         "config": {"workload": "COCO-80 608px: B=16 images/GPU, N=69354 anchors, C=80, <=20 GT/image; "
                                "FocalLoss module forward + backward (fused kernels)",
                    "global_batch": BATCH * world, "parallelism": f"dp{world}", "launch": launch,
-                   "eager_ms_per_step": eager_ms},
+                   "eager_ms_per_step": eager_ms,
+                   "ms_per_step_without_announcing_the_next_batch": plain_ms},
         "parity_ok": parity,
         "roofline": {"bound": "hbm",
                      "kernel": "focal_stream_kernel<5, false, %s>" % ("true" if prefetch else "false")
