@@ -914,7 +914,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
   if (tid == 0) s_special[0] = s_special[1] = 0;
   int turn = 0;
   const float k0l = -(1.0f - fc.alpha) * kLn2;
-  constexpr int UG = 2;   // unroll of the general (row-tracking) path: keeps registers low
+  // unroll of the general (row-tracking) path: keeps registers low (3: no change; 5, one float4
+  // at a time behind scheduling barriers: more than 96 registers, 131 against 119 us)
+  constexpr int UG = 2;
 
   // A workgroup takes one part of one tile: with many classes a tile's classification block is
   // cut into `parts` runs of part_vecs float4 (a multiple of the block size), so that every
