@@ -45,9 +45,11 @@ class PostprocessPipeline:
     as a sequence that makes each image's views on access).
 
     depth: batches that may be in flight (output buffers); streams: HIP streams they are spread
-    over.  Four streams is where the GPU-side gain levels off on MI355X; twice as many slots keep
-    those streams fed while the host waits for the oldest batch (608 px, 80 classes, 16 images:
-    78 us per batch with four slots, 69-71 with eight; 98 one batch at a time).
+    over.  Three streams and the default stream have a hardware queue each with HIP's four queues
+    per process: a fourth stream gains 2 % when the queues fall well and loses 5-10 % when two
+    streams share one, which is not under the caller's control.  Twice as many slots keep the
+    streams fed while the host waits for the oldest batch (608 px, 80 classes, 16 images:
+    77 us per batch with three slots, 70-73 with six; 98 one batch at a time).
     The remaining keyword arguments are those of ``retinahead.postprocess`` (``score_thresh``,
     ``iou_thresh``, ``mode``, ``pre_nms_topk``, ``max_det``, ``max_candidates``, ``from_logits``).
 
@@ -57,7 +59,7 @@ class PostprocessPipeline:
     is the number of batches submitted and not yet taken.
     """
 
-    def __init__(self, depth=8, streams=4, device=None, **kw):
+    def __init__(self, depth=6, streams=3, device=None, **kw):
         if depth < 1 or streams < 1:
             raise ValueError("depth and streams must be at least 1")
         streams = min(streams, depth)

@@ -11,8 +11,8 @@ anchors = rh.Anchors()(torch.zeros(1, 3, 608, 608, device=dev))
 n = anchors.shape[1]
 icls_np, ireg_np = bench.synth_infer(np.random.default_rng(3000), 16, n, 80)
 icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
-for depth in (4, 8, 12):
-    pipe = rh.PostprocessPipeline(depth=depth, streams=4)
+for depth, width in ((4, 4), (8, 4), (12, 4), (3, 3), (6, 3), (9, 3), (8, 4), (6, 3), (8, 4), (6, 3)):
+    pipe = rh.PostprocessPipeline(depth=depth, streams=width)
     ts, tr = [], []
     def run(k):
         for _ in range(k):
@@ -27,4 +27,4 @@ for depth in (4, 8, 12):
     t1 = time.perf_counter()
     run(400)
     total = (time.perf_counter() - t1) / 400 * 1e6
-    print(f"depth {depth}: {total:.1f} us/batch; submit median {np.median(ts)*1e6:.1f} us, results median {np.median(tr)*1e6:.1f} us (p90 {np.percentile(tr,90)*1e6:.1f})")
+    print(f"depth {depth} on {width} streams: {total:.1f} us/batch; submit median {np.median(ts)*1e6:.1f} us, results median {np.median(tr)*1e6:.1f} us (p90 {np.percentile(tr,90)*1e6:.1f})")
