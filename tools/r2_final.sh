@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 evidence: rocprofv3 summaries of bench.py and of the stage tool, three driver-style bench
+# evidence run: rocprofv3 summaries of bench.py and of the stage tool, three driver-style bench
 # runs, the configuration table
 cd $GRAFT_REPO_ROOT
 bash tools/collect_profiles.sh r02 > gpurun_out/collect_r02.log 2>&1 || { tail -20 gpurun_out/collect_r02.log; exit 1; }
