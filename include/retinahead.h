@@ -177,7 +177,11 @@ void rh_focal_params_default(rh_focal_params* p);
  * workspace's next assignment after the stages that still read it).
  * RH_STAGE_STREAM | RH_STAGE_FINALIZE in one call reduce inside the stream launch (no further
  * kernel); run apart they give the same bits.  Either way the workspace must have had its
- * RH_STAGE_ASSIGN since it was allocated or last used for another shape. */
+ * RH_STAGE_ASSIGN since it was allocated or last used for another shape.
+ * Zero-fill a workspace once before its first use (hipMemsetAsync): the reduction inside the
+ * launch tells the records of the current call from older bytes by a 32-bit tag that is never
+ * zero and changes with every call; bytes left behind by another user of the memory could carry
+ * the current tag by chance (2^-31 per record). */
 enum rh_focal_stage {
   RH_STAGE_ASSIGN = 1,   /* GT compaction + IoU assignment + num_pos            */
   RH_STAGE_STREAM = 2,   /* N x C focal stream + smooth-L1, losses and gradients */

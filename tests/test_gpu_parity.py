@@ -436,6 +436,27 @@ def test_final_reduction_inside_the_stream_launch(rh, bsz, size, c, m, valid, no
     assert torch.equal(late["losses"], apart["losses"]) and torch.equal(late["per_image"], apart["per_image"])
 
 
+@pytest.mark.parametrize("fill", [0xFF, 0x01, "random"])
+def test_loss_on_a_workspace_full_of_old_bytes(rh, fill):
+    """The workspace is caller-owned memory: whatever bytes it holds before the first call (all
+    ones would read as a valid odd tag; random bytes stand for another user's data), the assignment
+    stage starts a fresh tag and the in-launch reduction gives the bits of a zero-filled one."""
+    F = rh.functional
+    cls, reg, anc, ann = make_batch(77, 3, 192, 20, 5, [5, 0, 2])
+    d = [dev(x) for x in (cls, reg, anc, ann)]
+    clean = F.focal_loss_fwd_bwd(*d, ws=F.focal_workspace(3, anc.shape[1], 20, 5, torch.device("cuda:0")))
+    ws = F.focal_workspace(3, anc.shape[1], 20, 5, torch.device("cuda:0"))
+    if fill == "random":
+        ws.copy_(torch.randint(0, 256, ws.shape, dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).cuda())
+    else:
+        ws.fill_(fill)
+    for rep in range(2):
+        got = F.focal_loss_fwd_bwd(*d, ws=ws)
+        torch.cuda.synchronize()
+        for k in ("losses", "per_image", "num_pos", "d_classifications", "d_regressions"):
+            assert torch.equal(got[k], clean[k]), (k, rep)
+
+
 def test_loss_deterministic_and_unaligned(rh):
     cls, reg, anc, ann = make_batch(3, 2, 128, 80, 5, [5, 2])
     a = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
