@@ -106,6 +106,7 @@ class PostprocessPipeline:
                 and regression.dtype is torch.float32 and classification.is_contiguous()
                 and regression.is_contiguous() and classification.device == self.device
                 and regression.device == self.device and anchors.data_ptr() == out["call"][0]
+                and torch.cuda.current_device() == self.device.index   # the C call launches on it
                 and (height, width) == out["call"][1])
         if fast:
             # The slot has served this shape before: same checks, same buffers -- one C call.  Its
