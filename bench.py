@@ -360,6 +360,30 @@ def main():
         except Exception as e:                   # pragma: no cover - depends on the runtime
             print(f"[bench] plain-step graph failed ({e!r})", file=sys.stderr)
 
+    # two consecutive steps (A then B) captured as ONE graph: between two graph launches the GPU
+    # idles about 8 us (the marker that ends a launch), inside a graph the next kernel starts when
+    # the previous one ends -- what the path costs inside a training iteration captured whole
+    pair_ms = None
+    if graphs and prefetch and world == 1:
+        try:
+            cls.grad = None
+            reg.grad = None
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
+                local_step()
+                local_step()
+            times = []
+            for _ in range(12):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(max(args.steps // 2, 1)):
+                    g2.replay()
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t1) / (2 * max(args.steps // 2, 1)) * 1e3)
+            pair_ms = float(np.median(times[2:]))
+        except Exception as e:                   # pragma: no cover - depends on the runtime
+            print(f"[bench] two-step graph failed ({e!r})", file=sys.stderr)
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -552,7 +576,7 @@ def main():
                                "FocalLoss module forward + backward (fused kernels)",
                    "global_batch": BATCH * world, "parallelism": f"dp{world}", "launch": launch,
                    "eager_ms_per_step": eager_ms,
-                   "ms_per_step_without_announcing_the_next_batch": plain_ms},
+                   "ms_per_step_without_announcing_the_next_batch": plain_ms, "ms_per_step_two_steps_per_graph": pair_ms},
         "parity_ok": parity,
         "roofline": {"bound": "hbm",
                      "kernel": "focal_stream_kernel<5, false, %s>" % ("true" if prefetch else "false")
