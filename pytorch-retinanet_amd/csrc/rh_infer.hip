@@ -147,6 +147,12 @@ struct TileCands {
   u64* key;   // [64][num_tiles]  make_key(score, global row = image*N + anchor)
   int* lab;   // [64][num_tiles]  arg-max class
   int num_tiles;
+  // Flat layout with at least 65 rows per image (else null / 0): a tile holds rows of at most
+  // two images; split[j] = how many candidates of the tile that also holds the first rows of
+  // image j + 1 belong to image j (they come first in its list).  Written by every scan, so
+  // that readers need not look at the keys of an image's first and last tile to tell.
+  int* split;       // [batch]
+  int rows_per_image;
   __device__ __forceinline__ size_t at(int tile, int slot) const {
     return (size_t)slot * num_tiles + tile;
   }
@@ -166,7 +172,14 @@ __device__ __forceinline__ void emit_tile(const int tile, const int rows, const 
     tc.key[at] = make_key(score, (unsigned)(row0 + lane));
     tc.lab[at] = (int)key_index(best);
   }
-  if (lane == 0) tc.cnt[tile] = __popcll(m);
+  if (lane == 0) {
+    tc.cnt[tile] = __popcll(m);
+    if (tc.split) {
+      const int j = row0 / tc.rows_per_image;
+      const int b = (j + 1) * tc.rows_per_image - row0;     // rows of image j in this tile
+      if (b < rows) tc.split[j] = __popcll(m & ((1ull << b) - 1ull));
+    }
+  }
 }
 
 // Tile kernel: float4 stream over the tile.  A row is a candidate only if its maximum
@@ -883,7 +896,12 @@ constexpr int kRankKeys = 64 * kRankKpl;
 constexpr int kRankThreads = 512;
 constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankBatch = 3;   // groups of 64 tiles whose lists a wave loads together
-constexpr int kRankSlots = 4;   // list slots per tile loaded together
+#ifndef RH_RANK_SLOTS
+#define RH_RANK_SLOTS 4
+#endif
+// list slots per tile loaded together.  Measured, whole call on one stream: 2 or 4 slots 97.0 /
+// 97.4 us; 8 slots 106.4; 8 slots requesting only those a tile has filled 99.1
+constexpr int kRankSlots = RH_RANK_SLOTS;
 
 // mode 0: score >= mine, 1: score > mine, 2: full (score, index) key > mine; every list entry
 // read is compared with the lane's kRankKpl keys
@@ -963,6 +981,19 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
     // come last.
     const int chunk = ((t_hi - t_lo + kRankThreads) / kRankThreads) * 64;
     const int wb = min(t_lo + wave * chunk, t_hi + 1), we = min(wb + chunk, t_hi + 1);
+    // Does the image's first / last tile also hold rows of the previous / next image?  With
+    // the scan's split counts (or tile lists per image) the counting pass needs no keys.
+    const bool own_tiles = src.tiles_per_image > 0;
+    const bool lo_shared = !own_tiles && (first & 63) != 0;
+    const bool hi_shared = !own_tiles && ((last + 1) & 63) != 0 && j + 1 < batch;
+    int split_lo = 0, split_hi = 0;
+    if (tc.split) {
+      if (lo_shared) split_lo = tc.split[j - 1];
+      if (hi_shared) split_hi = tc.split[j];
+    }
+    // a wave whose tiles fit one batch of loads keeps their counts for the second pass
+    const bool one_batch = we - wb <= 64 * kRankBatch;
+    int craw[kRankBatch];
     int mine = 0, skip_lo = 0;
     for (int i0 = wb; i0 < we; i0 += 64 * kRankBatch) {
       int c[kRankBatch];
@@ -972,8 +1003,16 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
 #pragma unroll
       for (int u = 0; u < kRankBatch; ++u) {
         const int t = i0 + u * 64 + lane;
+        craw[u] = c[u];
         if (t >= we) c[u] = 0;
-        if (c[u] != 0 && (t == t_lo || t == t_hi)) {
+        if (own_tiles || tc.split) {
+          // (more than 64 rows per image: its first and last tile differ)
+          if (t == t_lo && lo_shared) {
+            skip_lo = min(split_lo, c[u]);
+            c[u] -= skip_lo;
+          }
+          if (t == t_hi && hi_shared) c[u] = min(split_hi, c[u]);
+        } else if (c[u] != 0 && (t == t_lo || t == t_hi)) {
           int m = 0, before = 0;
           for (int r0 = 0; r0 < c[u]; r0 += 8) {
             u64 k[8];
@@ -1007,9 +1046,14 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
     if (p0 >= min(found, cap) && blockIdx.y != 0) return;   // nothing to rank here (block-uniform)
     for (int i0 = wb; i0 < we; i0 += 64 * kRankBatch) {
       int c[kRankBatch], lo[kRankBatch], base[kRankBatch];
+      if (one_batch) {
 #pragma unroll
-      for (int u = 0; u < kRankBatch; ++u) c[u] = tc.cnt[min(i0 + u * 64 + lane, t_hi)];
-      __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < kRankBatch; ++u) c[u] = craw[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < kRankBatch; ++u) c[u] = tc.cnt[min(i0 + u * 64 + lane, t_hi)];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       int cm = 0;
 #pragma unroll
       for (int u = 0; u < kRankBatch; ++u) {
@@ -1943,6 +1987,7 @@ struct PostWorkspace {
   u64* sel_key;      // [B][cap] keys kept by the top-k pre-selection, their labels, their number
   int* sel_lab;
   int* sel_count;
+  int* split;        // [B] see TileCands
   size_t bytes;
 };
 
@@ -1964,6 +2009,7 @@ static PostWorkspace carve_post(void* ws, const NmsPlan& p, long long num_tiles)
   w.sel_key = cv.take<u64>(p.select ? (size_t)p.batch * p.cap : 0);
   w.sel_lab = cv.take<int>(p.select ? (size_t)p.batch * p.cap : 0);
   w.sel_count = cv.take<int>(p.select ? (size_t)p.batch : 0);
+  w.split = cv.take<int>((size_t)p.batch);
   w.bytes = cv.off;
   return w;
 }
@@ -2286,7 +2332,9 @@ int rh_postprocess(const float* classifications, const float* regressions, const
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const PostWorkspace w = carve_post(workspace, p, num_tiles);
-  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab, num_tiles};
+  const bool splits = n > kTileRows;
+  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab, num_tiles, splits ? w.split : nullptr,
+                     splits ? (int)n : 0};
   const int out_cap = q->max_det > 0 ? q->max_det : p.box_cap;
 
   if (stages & RH_POST_DECODE) {
@@ -2412,7 +2460,7 @@ int rh_postprocess_levels(const float* const* cls_levels, const float* const* re
   RH_REQUIRE(aligned16(workspace), RH_EALIGN, "workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const PostWorkspace w = carve_post(workspace, p, num_tiles);
-  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab, (int)num_tiles};
+  const TileCands tc{w.tile_cnt, w.tile_key, w.tile_lab, (int)num_tiles, nullptr, 0};
   const int out_cap = q->max_det > 0 ? q->max_det : p.box_cap;
 
   if (stages & RH_POST_DECODE) {
