@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Marginal cost of each post-processing stage with four batches in flight: the pipeline is run
+"""Marginal cost of each post-processing stage with three, two and one batches in flight: the pipeline is run
 with the score scan alone, with scan + sort, and with all stages."""
 import os, sys, time
 import numpy as np, torch
@@ -15,7 +15,7 @@ anchors = rh.Anchors()(torch.zeros(1, 3, 608, 608, device=dev))
 n = anchors.shape[1]
 icls_np, ireg_np = bench.synth_infer(np.random.default_rng(3000), B, n, 80)
 icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
-for ns in (4, 3):
+for ns in (3, 2, 1):
     for label, st in (("scan", _lib.POST_DECODE), ("scan+sort", _lib.POST_DECODE | _lib.POST_SORT), ("all", _lib.POST_ALL)):
         post = lambda out=None: F.postprocess_raw(icls, ireg, anchors, 608, 608, cand_cap=4096, out=out, stages=st)
         full = lambda out=None: F.postprocess_raw(icls, ireg, anchors, 608, 608, cand_cap=4096, out=out)
