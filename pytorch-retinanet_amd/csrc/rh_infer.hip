@@ -12,6 +12,7 @@
 // Compiled with -ffp-contract=off: box coordinates and IoU values decide integer
 // keep lists that must match a float32 CPU evaluation bit for bit.
 #include "rh_common.h"
+#include <atomic>
 #include <mutex>
 
 namespace rh {
@@ -887,12 +888,13 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(
 // score > mine for entries after them; only the block's own 64 entries need the full key.
 // The owner then decodes the box and writes (key, box, label) at its rank.
 // ---------------------------------------------------------------------------
-constexpr int kRankMax = 8192;   // 12 bytes of LDS per key: 96 KiB of the CU's 160
+constexpr int kRankMax = 8192;   // 14 bytes of LDS per key: 112 KiB of the CU's 160
 #ifndef RH_RANK_KPL
 #define RH_RANK_KPL 2
 #endif
-constexpr int kRankKpl = RH_RANK_KPL;       // keys per lane: clusters of 64 list entries per block
+constexpr int kRankKpl = RH_RANK_KPL;       // least keys per lane: clusters of 64 list entries per block
 constexpr int kRankKeys = 64 * kRankKpl;
+constexpr int kRankKplMax = 4;              // most clusters one pass of a block counts for
 constexpr int kRankThreads = 512;
 constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankBatch = 3;   // groups of 64 tiles whose lists a wave loads together
@@ -905,10 +907,10 @@ constexpr int kRankSlots = RH_RANK_SLOTS;
 
 // mode 0: score >= mine, 1: score > mine, 2: full (score, index) key > mine; every list entry
 // read is compared with the lane's kRankKpl keys
-template <int kMode>
+template <int kMode, int NC>
 __device__ __forceinline__ void rank_count(const unsigned* s_sk, const unsigned* s_ix, int qa,
-                                           const int qb, const unsigned (&mys)[kRankKpl],
-                                           const unsigned (&myx)[kRankKpl], int (&rank)[kRankKpl]) {
+                                           const int qb, const unsigned (&mys)[NC],
+                                           const unsigned (&myx)[NC], int (&rank)[NC]) {
   // eight entries per round as 16-byte LDS reads (uniform address: broadcast).  Every caller's
   // qa is a multiple of 8 whenever the range is not empty.
   for (; qa + 8 <= qb; qa += 8) {
@@ -926,7 +928,7 @@ __device__ __forceinline__ void rank_count(const unsigned* s_sk, const unsigned*
     for (int u = 0; u < 8; ++u) {
       const unsigned sk = sk8[u];
 #pragma unroll
-      for (int c = 0; c < kRankKpl; ++c) {
+      for (int c = 0; c < NC; ++c) {
         if (kMode == 0) rank[c] += sk >= mys[c];
         if (kMode == 1) rank[c] += sk > mys[c];
         if (kMode == 2) rank[c] += (((u64)sk << 32) | ix8[u]) > (((u64)mys[c] << 32) | myx[c]);
@@ -936,7 +938,7 @@ __device__ __forceinline__ void rank_count(const unsigned* s_sk, const unsigned*
   for (; qa < qb; ++qa) {
     const unsigned sk = s_sk[qa];
 #pragma unroll
-    for (int c = 0; c < kRankKpl; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (kMode == 0) rank[c] += sk >= mys[c];
       if (kMode == 1) rank[c] += sk > mys[c];
       if (kMode == 2) rank[c] += (((u64)sk << 32) | s_ix[qa]) > (((u64)mys[c] << 32) | myx[c]);
@@ -945,7 +947,150 @@ __device__ __forceinline__ void rank_count(const unsigned* s_sk, const unsigned*
 }
 
 __host__ __device__ inline int rank_lds_keys(int cap) { return (cap + 63) & ~63; }
-__host__ __device__ inline size_t rank_lds_bytes(int cap) { return (size_t)rank_lds_keys(cap) * 12; }
+__host__ __device__ inline size_t rank_lds_bytes(int cap) { return (size_t)rank_lds_keys(cap) * 14; }
+
+// The list bucketed by score: bin b (rank_bin, monotone in the score; kSelBins of them) owns the
+// slice [start[b], cursor[b]) of `idx`, list positions of its entries in no particular order, the
+// bins with the higher scores first.  A key's rank is start[its bin] plus the greater keys of
+// its own bin: a handful of comparisons instead of one with every entry of the list.
+#ifndef RH_BUCKET_ROUND
+#define RH_BUCKET_ROUND 1
+#endif
+// entries of a bin compared per round (whole call on one stream: 1: 92.6 us, 2: 94.1, 4: 93.5, 8: 93.4;
+// bins hold a few entries each)
+constexpr int kBucketRound = RH_BUCKET_ROUND;
+struct RankBuckets {
+  const int* start;
+  const int* cursor;
+  const unsigned short* idx;
+  bool on;      // block-uniform; off when some bin is so full that counting over the list is cheaper
+};
+__device__ __forceinline__ int rank_bin(const unsigned score_key) {
+  const int b = (int)(score_key >> 16) - (int)((0x3D000000u ^ 0x80000000u) >> 16);
+  return min(max(b, 0), kSelBins - 1);
+}
+
+// One pass of a rank-sort block: counts the ranks of the NC clusters [c0, c0 + NC) of image j's
+// list (in LDS: s_sk, s_ix, s_lab; K entries) and writes what the NMS stage reads for them.
+template <int NC>
+__device__ __forceinline__ void rank_pass(const int c0, const bool writes_counters, const int j,
+                                          const int K, const int ke, const int found,
+                                          const int cap, const int batch,
+                                          const unsigned* s_sk, const unsigned* s_ix,
+                                          const int* s_lab, int (*s_part)[64 * kRankKplMax],
+                                          int* __restrict__ counters, const SortSrc& src,
+                                          const SortOut& so, const RankBuckets bk) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p0 = c0 * 64;
+  if (!bk.on) {
+  // lane l counts for list entries p0 + c*64 + l, c < NC: one pass over the list serves them all
+  unsigned mys[NC], myx[NC];
+  int rank[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int pc = min(p0 + c * 64 + lane, max(K - 1, 0));
+    mys[c] = s_sk[pc];
+    myx[c] = s_ix[pc];
+    rank[c] = 0;
+  }
+  // wave w counts in [q0, q1): equal shares of the list, multiples of 8 entries
+  const int seg = ((K + 8 * kRankWaves - 1) / (8 * kRankWaves)) << 3;
+  const int q0 = min(wave * seg, K), q1 = min(q0 + seg, K);
+  if (src.from_tiles && (src.tiles_per_image > 0 || src.list_key)) {
+    rank_count<2, NC>(s_sk, s_ix, q0, q1, mys, myx, rank);      // list not in anchor order: full keys
+  } else {
+    rank_count<0, NC>(s_sk, s_ix, q0, min(q1, p0), mys, myx, rank);
+    rank_count<2, NC>(s_sk, s_ix, max(q0, p0), min(q1, p0 + NC * 64), mys, myx, rank);
+    rank_count<1, NC>(s_sk, s_ix, max(q0, p0 + NC * 64), q1, mys, myx, rank);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s_part[wave][c * 64 + lane] = rank[c];
+  }
+  // The pair kernel ORs bits into the predecessor words: zero the words of the ranks
+  // [p0, p0 + NC * 64) (whichever keys end up there), for rank r the words 0 .. r/64, one
+  // 512-byte row per store.
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int r = p0 + c * 64 + lane;
+    if (r < ke)
+      for (int w = wave; w <= c0 + c; w += kRankWaves)
+        so.mask[((size_t)j * so.wstride + w) * so.box_stride + r] = 0ull;
+  }
+  if (!bk.on) __syncthreads();      // (block-uniform) the partial counts
+  RH_TL(0, 3);
+  if (wave < NC) {            // wave c finishes cluster c of the pass
+    const int cluster = c0 + wave;
+    const int p = p0 + wave * 64 + lane;
+    const int pc = min(p, max(K - 1, 0));
+    const unsigned ms = s_sk[pc], mx = s_ix[pc];
+    int rk = 0;
+    if (bk.on) {
+      const int b = rank_bin(ms);
+      const u64 mykey = ((u64)ms << 32) | (u64)mx;
+      const int qe = bk.cursor[b];
+      int q = p < K ? bk.start[b] : qe;
+      rk = q;                                  // the entries of the bins above
+      for (; q < qe; q += kBucketRound) {    // the reads of a round do not depend on each other
+        int e[kBucketRound];
+#pragma unroll
+        for (int u = 0; u < kBucketRound; ++u) e[u] = bk.idx[min(q + u, qe - 1)];
+        unsigned es[kBucketRound], ex[kBucketRound];
+#pragma unroll
+        for (int u = 0; u < kBucketRound; ++u) {
+          es[u] = s_sk[e[u]];
+          ex[u] = s_ix[e[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kBucketRound; ++u)
+          rk += q + u < qe && ((((u64)es[u]) << 32) | (u64)ex[u]) > mykey;
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < kRankWaves; ++w) rk += s_part[w][wave * 64 + lane];
+    }
+    const bool passed = p < K && rk < ke;      // else beyond the list, or cut by the top-k
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < K) {
+      const size_t q = (size_t)j * so.list_stride + p;
+      if (passed) {
+        const size_t o = (size_t)j * so.box_stride + rk;
+        so.keys[(size_t)j * so.key_stride + rk] = ((u64)ms << 32) | (u64)mx;
+        const unsigned idx = 0xFFFFFFFFu - mx;
+        if (src.from_tiles) {
+          const unsigned n = idx - (unsigned)j * (unsigned)src.N;
+          box = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
+                         src.height);
+        } else {
+          box = src.boxes[idx];
+        }
+        so.sbox[o] = box;
+        so.cbox[q] = box;
+        so.slabel[o] = s_lab[p];
+        for (int g = 0; g < so.nzw; ++g) so.nz[o * so.nzw + g] = 0ull;
+      }
+      so.cinfo[q] = make_int4(passed ? rk : -1, s_lab[p],
+                              __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
+    }
+    // each 64 list entries are one cluster of the pair kernel
+    if (cluster < so.clusters) {
+      const ClusterSummary cs = summarize_cluster(box, passed);
+      if (lane == 0) {
+        float4* out = so.csum + ((size_t)j * so.clusters + cluster) * 2;
+        out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
+        out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
+      }
+    }
+    if (writes_counters && wave == 0 && lane == 0) {
+      if (!src.list_key) {           // (the selection kernel has written these two)
+        counters[j] = found;
+        counters[batch + j] = max(found - cap, 0);
+      }
+      counters[2 * batch + j] = ke;
+    }
+    RH_TL(0, 4);
+  }
+}
 
 __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict__ counters, int batch,
                                                                  int cap, int topk, SortSrc src,
@@ -957,15 +1102,29 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   unsigned* s_ix = s_dyn + rank_lds_keys(cap);
   int* s_lab = reinterpret_cast<int*>(s_dyn + 2 * rank_lds_keys(cap));
   __shared__ int s_wsum[kRankWaves];
-  __shared__ int s_part[kRankWaves][kRankKeys];
+  __shared__ int s_part[kRankWaves][64 * kRankKplMax];
+  __shared__ int s_start[kSelBins], s_cursor[kSelBins], s_ctot[kSelBins / 64], s_big;
   // the image index is the fast grid dimension: blocks beyond an image's candidate count
   // (most of the grid when the lists are far from full) are dispatched last and exit at once
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p0 = blockIdx.y * kRankKeys;
+  // The grid holds gridDim.y blocks per image, sized by the host to the machine rather than to
+  // the list capacity; the image's clusters are dealt to them evenly once the list's length is
+  // known (at least kRankKpl per block, so short lists leave the later blocks without work).
+  auto clusters_per_block = [&](const int k) {
+    return max(kRankKpl, (((k + 63) >> 6) + (int)gridDim.y - 1) / (int)gridDim.y);
+  };
+  auto nothing_to_rank = [&](const int found_now) {     // block-uniform
+    const int k = min(found_now, cap);
+    return blockIdx.y != 0 && (int)blockIdx.y * clusters_per_block(k) * 64 >= k;
+  };
   RH_TL(0, 0);
+  // score histogram of the list (see RankBuckets), filled as the entries arrive in LDS; the
+  // barriers of the list's construction order the zeroing before the first increment
+  for (int b = tid; b < kSelBins; b += kRankThreads) s_cursor[b] = 0;
+  if (tid == 0) s_big = 0;
   int found;
   if (src.from_tiles && !src.list_key) {
     const TileCands tc = src.tc;
@@ -1043,7 +1202,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
       found += s_wsum[w];
     }
     RH_TL(0, 1);
-    if (p0 >= min(found, cap) && blockIdx.y != 0) return;   // nothing to rank here (block-uniform)
+    if (nothing_to_rank(found)) return;
     for (int i0 = wb; i0 < we; i0 += 64 * kRankBatch) {
       int c[kRankBatch], lo[kRankBatch], base[kRankBatch];
       if (one_batch) {
@@ -1095,6 +1254,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
             const int pos = base[u] + rr - lo[u];
             if (rr >= lo[u] && rr < c[u] && g <= last && pos < cap) {
               s_sk[pos] = (unsigned)(k[u][r] >> 32);
+              atomicAdd(&s_cursor[rank_bin((unsigned)(k[u][r] >> 32))], 1);
               s_ix[pos] = (unsigned)k[u][r];
               s_lab[pos] = l[u][r];
             }
@@ -1104,19 +1264,23 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
     }
   } else if (src.list_key) {
     found = src.list_count[j];
-    if (p0 >= min(found, cap) && blockIdx.y != 0) return;
+    if (nothing_to_rank(found)) return;
+    __syncthreads();                      // the histogram is zero
     for (int i = tid; i < min(found, cap); i += kRankThreads) {
       const u64 k = src.list_key[(size_t)j * cap + i];
       s_sk[i] = (unsigned)(k >> 32);
+      atomicAdd(&s_cursor[rank_bin((unsigned)(k >> 32))], 1);
       s_ix[i] = (unsigned)k;
       s_lab[i] = src.list_lab[(size_t)j * cap + i];
     }
   } else {
     found = src.count;
-    if (p0 >= min(found, cap) && blockIdx.y != 0) return;
+    if (nothing_to_rank(found)) return;
+    __syncthreads();                      // the histogram is zero
     for (int i = tid; i < min(found, cap); i += kRankThreads) {
       const u64 k = make_key(src.scores[i], (unsigned)i);
       s_sk[i] = (unsigned)(k >> 32);
+      atomicAdd(&s_cursor[rank_bin((unsigned)(k >> 32))], 1);
       s_ix[i] = (unsigned)k;
       s_lab[i] = src.labels ? src.labels[i] : 0;
     }
@@ -1125,89 +1289,58 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   RH_TL(0, 2);
   const int K = min(found, cap);
   const int ke = topk > 0 ? min(K, topk) : K;
-  // lane l counts for list entries p0 + c*64 + l, c < kRankKpl: one pass over the list serves
-  // them all
-  unsigned mys[kRankKpl], myx[kRankKpl];
-  int rank[kRankKpl];
+  // ---- bucket the list by score: counts per bin, bins laid out from the highest down, then
+  // every entry's list position into its bin's slice
+  unsigned short* b_idx = reinterpret_cast<unsigned short*>(s_dyn + 3 * rank_lds_keys(cap));
+  {
+    const int limit = max(64, K >> 3);      // a fuller bin: counting over the whole list is cheaper
+    int h[2], incl[2];
 #pragma unroll
-  for (int c = 0; c < kRankKpl; ++c) {
-    const int pc = min(p0 + c * 64 + lane, max(K - 1, 0));
-    mys[c] = s_sk[pc];
-    myx[c] = s_ix[pc];
-    rank[c] = 0;
-  }
-  // wave w counts in [q0, q1): equal shares of the list, multiples of 8 entries
-  const int seg = ((K + 8 * kRankWaves - 1) / (8 * kRankWaves)) << 3;
-  const int q0 = min(wave * seg, K), q1 = min(q0 + seg, K);
-  if (src.from_tiles && (src.tiles_per_image > 0 || src.list_key)) {
-    rank_count<2>(s_sk, s_ix, q0, q1, mys, myx, rank);      // list not in anchor order: full keys
-  } else {
-    rank_count<0>(s_sk, s_ix, q0, min(q1, p0), mys, myx, rank);
-    rank_count<2>(s_sk, s_ix, max(q0, p0), min(q1, p0 + kRankKeys), mys, myx, rank);
-    rank_count<1>(s_sk, s_ix, max(q0, p0 + kRankKeys), q1, mys, myx, rank);
-  }
+    for (int u = 0; u < 2; ++u) {
+      const int ch = wave + u * kRankWaves;                       // 64 bins, from the top
+      h[u] = ch < kSelBins / 64 ? s_cursor[kSelBins - 1 - (ch * 64 + lane)] : 0;
+      incl[u] = h[u];
 #pragma unroll
-  for (int c = 0; c < kRankKpl; ++c) s_part[wave][c * 64 + lane] = rank[c];
-  // The pair kernel ORs bits into the predecessor words: zero the words of the ranks
-  // [p0, p0 + kRankKeys) (whichever keys end up there), for rank r the words 0 .. r/64, one
-  // 512-byte row per store.
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl[u], d, 64);
+        if (lane >= d) incl[u] += o;
+      }
+      if (ch < kSelBins / 64 && lane == 63) s_ctot[ch] = incl[u];
+      if (h[u] > limit) s_big = 1;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int c = 0; c < kRankKpl; ++c) {
-    const int r = p0 + c * 64 + lane;
-    if (r < ke)
-      for (int w = wave; w <= (int)blockIdx.y * kRankKpl + c; w += kRankWaves)
-        so.mask[((size_t)j * so.wstride + w) * so.box_stride + r] = 0ull;
+    for (int u = 0; u < 2; ++u) {
+      const int ch = wave + u * kRankWaves;
+      if (ch < kSelBins / 64) {
+        int off = 0;
+        for (int c = 0; c < ch; ++c) off += s_ctot[c];
+        const int b = kSelBins - 1 - (ch * 64 + lane);
+        s_start[b] = off + incl[u] - h[u];
+        s_cursor[b] = off + incl[u] - h[u];
+      }
+    }
   }
+  const bool bucketed = s_big == 0;
   __syncthreads();
-  RH_TL(0, 3);
-  if (wave < kRankKpl) {            // wave c finishes cluster c of the block
-    const int cluster = (int)blockIdx.y * kRankKpl + wave;
-    const int p = p0 + wave * 64 + lane;
-    const int pc = min(p, max(K - 1, 0));
-    const unsigned ms = s_sk[pc], mx = s_ix[pc];
-    int rk = 0;
-#pragma unroll
-    for (int w = 0; w < kRankWaves; ++w) rk += s_part[w][wave * 64 + lane];
-    const bool passed = p < K && rk < ke;      // else beyond the list, or cut by the top-k
-    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p < K) {
-      const size_t q = (size_t)j * so.list_stride + p;
-      if (passed) {
-        const size_t o = (size_t)j * so.box_stride + rk;
-        so.keys[(size_t)j * so.key_stride + rk] = ((u64)ms << 32) | (u64)mx;
-        const unsigned idx = 0xFFFFFFFFu - mx;
-        if (src.from_tiles) {
-          const unsigned n = idx - (unsigned)j * (unsigned)src.N;
-          box = clip_box(decode_box(src.anchors[n], load_deltas(src, j, n, idx), src.bc), src.width,
-                         src.height);
-        } else {
-          box = src.boxes[idx];
-        }
-        so.sbox[o] = box;
-        so.cbox[q] = box;
-        so.slabel[o] = s_lab[p];
-        for (int g = 0; g < so.nzw; ++g) so.nz[o * so.nzw + g] = 0ull;
-      }
-      so.cinfo[q] = make_int4(passed ? rk : -1, s_lab[p],
-                              __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
-    }
-    // each 64 list entries are one cluster of the pair kernel
-    if (cluster < so.clusters) {
-      const ClusterSummary cs = summarize_cluster(box, passed);
-      if (lane == 0) {
-        float4* out = so.csum + ((size_t)j * so.clusters + cluster) * 2;
-        out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
-        out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
-      }
-    }
-    if (blockIdx.y == 0 && wave == 0 && lane == 0) {
-      if (!src.list_key) {           // (the selection kernel has written these two)
-        counters[j] = found;
-        counters[batch + j] = max(found - cap, 0);
-      }
-      counters[2 * batch + j] = ke;
-    }
-    RH_TL(0, 4);
+  if (bucketed) {
+    for (int i = tid; i < K; i += kRankThreads)
+      b_idx[atomicAdd(&s_cursor[rank_bin(s_sk[i])], 1)] = (unsigned short)i;
+    __syncthreads();
+  }
+  const RankBuckets bk{s_start, s_cursor, b_idx, bucketed};
+  const int kpl = clusters_per_block(K);
+  const int c_end = min(((int)blockIdx.y + 1) * kpl, (K + 63) >> 6);
+  bool first = true;
+  for (int c0 = (int)blockIdx.y * kpl; first || c0 < c_end; c0 += kRankKplMax) {
+    const bool wc = first && blockIdx.y == 0;
+    const int nc = max(min(kRankKplMax, c_end - c0), 1);      // block-uniform
+    if (!first) __syncthreads();                              // s_part is reused
+    if (nc == 1) rank_pass<1>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
+    else if (nc == 2) rank_pass<2>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
+    else if (nc == 3) rank_pass<3>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
+    else rank_pass<4>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
+    first = false;
   }
 }
 
@@ -2042,6 +2175,23 @@ static int allow_lds(Kernel kernel, size_t bytes) {
   return RH_OK;
 }
 
+// Compute units of the current device (asked once per device).
+static int compute_units(int* out) {
+  constexpr int kMaxDevices = 64;
+  static std::atomic<int> cached[kMaxDevices];
+  int device = -1;
+  RH_CHECK_HIP(hipGetDevice(&device));
+  RH_REQUIRE(device >= 0 && device < kMaxDevices, RH_EINVAL, "device %d out of range", device);
+  int n = cached[device].load(std::memory_order_relaxed);
+  if (n == 0) {
+    RH_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+    RH_REQUIRE(n > 0, RH_ELAUNCH, "device reports %d compute units", n);
+    cached[device].store(n, std::memory_order_relaxed);
+  }
+  *out = n;
+  return RH_OK;
+}
+
 static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const SortSrc& src,
                        hipStream_t s) {
   const SortOut so = sort_out(p, w);
@@ -2057,7 +2207,14 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
     }
     const size_t lds = rank_lds_bytes(p.cap);
     if (int e = allow_lds(sort_rank_kernel, lds)) return e;
-    hipLaunchKernelGGL(sort_rank_kernel, dim3(p.batch, (p.cap + kRankKeys - 1) / kRankKeys),
+    // Blocks per image: as many as the capacity could need at kRankKpl clusters each, but no
+    // more than gives every compute unit one block -- a second block on a unit (even one that
+    // finds nothing to rank) slows the first: 16 images x 32 blocks, half of them without work,
+    // 16.6 us; 16 x 16 blocks 13.0 us.  Longer lists then take more clusters per block.
+    int cus = 0;
+    if (int e = compute_units(&cus)) return e;
+    const int per_image = std::min((p.cap + kRankKeys - 1) / kRankKeys, std::max(1, cus / p.batch));
+    hipLaunchKernelGGL(sort_rank_kernel, dim3(p.batch, per_image),
                        dim3(kRankThreads), lds, s, w.counters, p.batch, p.cap, topk, from, so);
     RH_CHECK_LAUNCH("sort_rank_kernel");
     return RH_OK;

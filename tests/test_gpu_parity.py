@@ -853,6 +853,28 @@ def test_nms_vs_oracle(rh, k):
     assert np.array_equal(keep2, O.nms(boxes, scores, 0.3))
 
 
+@pytest.mark.parametrize("kind", ["one_bin", "two_values", "below_the_bins", "logits", "wide"])
+def test_nms_score_distributions_of_the_rank_sort(rh, kind):
+    """The rank sort buckets the list by the scores' upper bits and compares a key only inside its
+    bin; a bin too full for that (equal scores, scores below 1/32 or above 1) sends the block back
+    to counting over the whole list.  Either way: ranks by (score, lower index first)."""
+    k = 3000
+    boxes, scores = rand_dets(11, k)
+    rng = np.random.default_rng(12)
+    if kind == "one_bin":
+        scores[:] = 0.5
+    elif kind == "two_values":
+        scores[:] = np.where(rng.random(k) < 0.5, 0.25, 0.75)
+    elif kind == "below_the_bins":
+        scores[:] = rng.random(k).astype(np.float32) * 0.03
+    elif kind == "logits":
+        scores[:] = rng.normal(0, 4, k).astype(np.float32)
+    else:
+        scores[:] = np.exp(rng.uniform(np.log(0.04), 0, k)).astype(np.float32)
+    keep = rh.nms(dev(boxes), dev(scores), 0.5).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes, scores, 0.5))
+
+
 def test_nms_legacy_and_per_class(rh):
     boxes, scores = rand_dets(77, 700)
     dets = np.concatenate([boxes, scores[:, None]], 1)

@@ -17,7 +17,7 @@ n = anchors.shape[1]
 icls_np, ireg_np = bench.synth_infer(np.random.default_rng(3000), 16, n, 80)
 icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
 def post(out=None, stages=L.POST_ALL):
-    return F.postprocess_raw(icls, ireg, anchors, 608, 608, cand_cap=4096, out=out, stages=stages)
+    return F.postprocess_raw(icls, ireg, anchors, 608, 608, cand_cap=int(os.environ.get("RH_CAP", "4096")), out=out, stages=stages)
 res = post()
 ref = {k: v.clone() for k, v in res.items() if torch.is_tensor(v)}
 def train(fn, launches=20, reps=10):
