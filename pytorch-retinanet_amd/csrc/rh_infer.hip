@@ -878,15 +878,21 @@ __global__ __launch_bounds__(kSelThreads) void topk_select_kernel(
 // Rank sort for candidate lists of up to kRankMax keys per image.  Keys are unique (the
 // index is part of the key), so a key's position in descending order is the number of keys
 // greater than it: no exchange network, no serial dependency, and the work spreads over the
-// whole chip instead of one workgroup per image.
-// Block (x, j) ranks 64 keys of image j.  Every block of an image first rebuilds the same
-// candidate list in LDS (tile lists compacted in tile order by a block-wide prefix sum, so
-// all blocks see one order, which is ascending anchor index), then lane l owns list entry
-// x*64 + l and each of the four waves counts the greater keys in its quarter of the list
-// (uniform addresses: LDS broadcast reads).  Because the list is in index order, "greater"
-// is a 32-bit test on the score alone: score >= mine for entries before the block's own 64,
-// score > mine for entries after them; only the block's own 64 entries need the full key.
-// The owner then decodes the box and writes (key, box, label) at its rank.
+// chip instead of one workgroup per image.
+// The grid holds a fixed number of blocks per image (at most one block per compute unit in
+// all).  Every block of an image first rebuilds the same candidate list in LDS (tile lists
+// compacted in tile order by a block-wide prefix sum, so all blocks see one order, which is
+// ascending anchor index) and a histogram of the scores' upper 16 bits with it; the bins, laid
+// out from the highest score down, then receive the list positions of their entries
+// (RankBuckets).  The image's clusters of 64 list entries are dealt evenly to its blocks; a
+// wave takes a cluster, lane l its entry l, whose rank is the number of entries in the bins
+// above plus the greater keys in its own bin -- a handful of comparisons.  The owner then
+// decodes the box and writes (key, box, label) at its rank.
+// When some bin is too full for that (equal scores, scores outside (1/32, 1]) the block counts
+// over the whole list instead: each of its eight waves counts, for the block's entries, the
+// greater keys in its eighth of the list (uniform addresses: LDS broadcast reads; because the
+// list is in index order, "greater" is a 32-bit test on the score alone outside the block's
+// own entries).
 // ---------------------------------------------------------------------------
 constexpr int kRankMax = 8192;   // 14 bytes of LDS per key: 112 KiB of the CU's 160
 #ifndef RH_RANK_KPL
@@ -894,7 +900,15 @@ constexpr int kRankMax = 8192;   // 14 bytes of LDS per key: 112 KiB of the CU's
 #endif
 constexpr int kRankKpl = RH_RANK_KPL;       // least keys per lane: clusters of 64 list entries per block
 constexpr int kRankKeys = 64 * kRankKpl;
-constexpr int kRankKplMax = 4;              // most clusters one pass of a block counts for
+#ifndef RH_RANK_KPL_MAX
+#define RH_RANK_KPL_MAX 4
+#endif
+// Most clusters one pass of a block handles (at most its 8 waves).  Measured with the bucketed
+// ranks, whole call on one stream / three batches in flight: (kRankKpl, kRankKplMax) = (2, 4) 92.4 /
+// 68.4 us; (4, 4) 92.6 / 68.0-72.4; (4, 8) 92.9 / 68.3; (8, 8) 94.7 / 68.4-72.6.  Requesting the
+// first pass's anchors and regressions before the bucketing (with barriers that do not wait for
+// global loads) changed nothing.
+constexpr int kRankKplMax = RH_RANK_KPL_MAX;
 constexpr int kRankThreads = 512;
 constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankBatch = 3;   // groups of 64 tiles whose lists a wave loads together
@@ -1336,10 +1350,17 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
     const bool wc = first && blockIdx.y == 0;
     const int nc = max(min(kRankKplMax, c_end - c0), 1);      // block-uniform
     if (!first) __syncthreads();                              // s_part is reused
-    if (nc == 1) rank_pass<1>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
-    else if (nc == 2) rank_pass<2>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
-    else if (nc == 3) rank_pass<3>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
-    else rank_pass<4>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters, src, so, bk);
+#define RH_RANK_PASS(n)                                                                       \
+  case n:                                                                                     \
+    if constexpr (n <= kRankKplMax)                                                           \
+      rank_pass<n>(c0, wc, j, K, ke, found, cap, batch, s_sk, s_ix, s_lab, s_part, counters,  \
+                   src, so, bk);                                                              \
+    break;
+    switch (nc) {
+      RH_RANK_PASS(1) RH_RANK_PASS(2) RH_RANK_PASS(3) RH_RANK_PASS(4)
+      RH_RANK_PASS(5) RH_RANK_PASS(6) RH_RANK_PASS(7) RH_RANK_PASS(8)
+    }
+#undef RH_RANK_PASS
     first = false;
   }
 }
@@ -1545,7 +1566,11 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
   const int j = blockIdx.x % batch;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int A = (int)(blockIdx.x / batch) / slices, slice = (int)(blockIdx.x / batch) % slices;
+  // A block's units (cluster A, slice) are blockIdx.x / batch, then every gridDim.x / batch
+  // further: the grid need not be as large as the list capacity would allow.
+  const int unit_step = (int)(gridDim.x / batch);
+  int unit = (int)(blockIdx.x / batch);
+  int A = unit / slices, slice = unit % slices;
   RH_TL(1, 0);
   const float4* bj = cbox + (size_t)j * list_stride;
   const int4* ij = cinfo + (size_t)j * list_stride;
@@ -1564,10 +1589,10 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
     r.area = __int_as_float(info.z);
     return r;
   };
-  PairLane me = load_lane(A);
-  const float4 a_box = sj[A * 2], a_rng = sj[A * 2 + 1];          // uniform
-  const int first_b = min(A + lane, clusters - 1);
-  const float4 b_box0 = sj[first_b * 2], b_rng0 = sj[first_b * 2 + 1];
+  PairLane me = load_lane(min(A, clusters - 1));
+  float4 a_box = sj[min(A, clusters - 1) * 2], a_rng = sj[min(A, clusters - 1) * 2 + 1];   // uniform
+  int first_b = min(A + lane, clusters - 1);
+  float4 b_box0 = sj[first_b * 2], b_rng0 = sj[first_b * 2 + 1];
   __builtin_amdgcn_sched_barrier(0);
   // ranked: the list is what the rank sort saw; else the boxes are in rank order themselves
   // (list_len: the entries the rank sort was given -- all candidates found, or those the
@@ -1575,12 +1600,20 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
   const int klist = ranked ? min(list_len[j], cap) : counters[2 * batch + j];
   const int C = (klist + 63) >> 6;
   RH_TL(1, 1);
-  if (A >= C) return;
-  if (A * 64 + lane >= klist) me.rank = -1;
-
   const float f = fminf(thresh, 1.0f) * 0.9999f;
   const float c_hi = thresh * (1.0f + 4.8e-7f);
   const float k_filter = thresh / (1.0f + thresh) * (1.0f - 1.9e-6f);
+  for (; A < C; unit += unit_step, A = unit / slices, slice = unit % slices) {
+  if (unit != (int)(blockIdx.x / batch)) {       // (the first unit's records were requested above)
+    me = load_lane(A);
+    a_box = sj[A * 2];
+    a_rng = sj[A * 2 + 1];
+    first_b = min(A + lane, clusters - 1);
+    b_box0 = sj[first_b * 2];
+    b_rng0 = sj[first_b * 2 + 1];
+  }
+  if (A * 64 + lane >= klist) me.rank = -1;
+
   const float4 mine = me.box;
   const float area = me.area;
   const bool valid = me.rank >= 0;
@@ -1704,12 +1737,14 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
       RH_TL_DO(tl_a += wall_clock64() - tl_t;)
     }
   }
+  RH_TL_DO(if (unit + unit_step < C * slices) continue;)   // (stamps: the block's last unit)
   RH_TL(1, 3);
   RH_TL_VALUE(1, 9, (long long)__builtin_amdgcn_s_memtime());
   RH_TL_VALUE(1, 4, tl_tiles);
   RH_TL_VALUE(1, 5, tl_surv);
   RH_TL_VALUE(1, 6, tl_a);
   RH_TL_VALUE(1, 7, tl_set * 1000 + tl_nset);
+  }
 }
 
 // Cluster summaries, list records and zeroed mask words for sort paths that do not provide them
@@ -2255,12 +2290,21 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
                          w.slabel, keff, w.csum, w.cinfo, w.mask, p.box_cap, p.wstride, p.clusters);
       RH_CHECK_LAUNCH("cluster_prepare_kernel");
     }
-    // `slices` blocks (4 waves each) share the cluster pairs of one cluster
+    // `slices` blocks (4 waves each) share the cluster pairs of one cluster (the bench workload
+    // above with 1 / 2 / 4 / 8 slices: 96.0 / 93.3 / 95.9 / 99.7 us per call)
     int slices = 1;                                   // a power of two (the kernel masks with it)
     while (slices < 8 && slices * 64 <= p.clusters) slices *= 2;
     RH_REQUIRE((long long)p.clusters * slices * p.batch < (1ll << 31), RH_ESHAPE, "too many NMS workgroups");
     auto kern = per_class ? nms_pairs_kernel<true> : nms_pairs_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.clusters * slices * p.batch)), dim3(kThreads), 0, s,
+    // Blocks per image: enough for three quarters of the list capacity at one unit (cluster,
+    // slice) each; the blocks of a longer list take a second unit.  Lists are mostly well below
+    // the capacity, and blocks that find no unit still cost their dispatch, above all while other
+    // batches' kernels are being dispatched too (608 px, 16 images, about 2 000 of 4 096 candidates,
+    // whole call on one stream / three batches in flight: all units 93.4 / 68.4 us, three
+    // quarters 92.7 / 67.8, half 93.6 / 67.3, a quarter 97.5 / 70).
+    const int all_units = p.clusters * slices;
+    const int units = all_units >= 8 ? (all_units * 3 + 3) / 4 : all_units;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(units * p.batch)), dim3(kThreads), 0, s,
                        p.ranked ? w.cbox : w.sbox, w.cinfo, w.csum, w.counters,
                        p.select ? w.sel_count : w.counters, p.batch, w.mask, w.nz,
                        p.cap, p.ranked ? p.cap : p.box_cap, p.clusters, p.box_cap, p.wstride, p.nzw,
