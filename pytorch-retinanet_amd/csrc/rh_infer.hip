@@ -1933,12 +1933,22 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
     u64 bits[kCached];
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
-      // (rows clamped by the arrays' size, not by K: these loads go out beside the load of K)
-      const int row = min((s * kResolveWaves + wave) * 64 + lane, box_stride - 1);
-      bits[s] = nj[(size_t)row * nzw];
-      okey[s] = kj[row];
-      obox[s] = bj[row];
-      olab[s] = lj ? lj[row] : 0;
+      // The first two slots (2 048 boxes) are requested beside the load of K, rows clamped by
+      // the arrays' size; the further ones only where the list reaches them, once K is known
+      // (lists are mostly well below the capacity the slots are sized for).
+      const int c = s * kResolveWaves + wave;
+      const int row = min(c * 64 + lane, box_stride - 1);
+      if (s < 2 || c < W) {
+        bits[s] = nj[(size_t)row * nzw];
+        okey[s] = kj[row];
+        obox[s] = bj[row];
+        olab[s] = lj ? lj[row] : 0;
+      } else {
+        bits[s] = 0ull;
+        okey[s] = 0ull;
+        obox[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        olab[s] = 0;
+      }
     }
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
@@ -1956,8 +1966,11 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       pr[s].i1 = has1 ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
       b &= b - 1ull;
       pr[s].more = b != 0ull;
-      const u64 x = mj[(size_t)pr[s].i0 * box_stride + row];
-      const u64 y = mj[(size_t)pr[s].i1 * box_stride + row];
+      u64 x = 0ull, y = 0ull;
+      if (s < 2 || c < W) {
+        x = mj[(size_t)pr[s].i0 * box_stride + row];
+        y = mj[(size_t)pr[s].i1 * box_stride + row];
+      }
       pr[s].w0 = has0 ? x & earlier_bits(pr[s].i0, c * 64 + lane) : 0ull;
       pr[s].w1 = has1 ? y & earlier_bits(pr[s].i1, c * 64 + lane) : 0ull;
     }
