@@ -2315,8 +2315,10 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
     // batches' kernels are being dispatched too (608 px, 16 images, about 2 000 of 4 096 candidates,
     // whole call on one stream / three batches in flight: all units 93.4 / 68.4 us, three
     // quarters 92.7 / 67.8, half 93.6 / 67.3, a quarter 97.5 / 70).
+    // (Only for grids of more than 1 024 blocks: for two images with full lists the second
+    // units cost the pair kernel 31 instead of 20 us.)
     const int all_units = p.clusters * slices;
-    const int units = all_units >= 8 ? (all_units * 3 + 3) / 4 : all_units;
+    const int units = (long long)all_units * p.batch > 1024 ? (all_units * 3 + 3) / 4 : all_units;
     hipLaunchKernelGGL(kern, dim3((unsigned)(units * p.batch)), dim3(kThreads), 0, s,
                        p.ranked ? w.cbox : w.sbox, w.cinfo, w.csum, w.counters,
                        p.select ? w.sel_count : w.counters, p.batch, w.mask, w.nz,
