@@ -1556,8 +1556,12 @@ struct PairLane {
   float area;
 };
 
+#ifndef RH_PAIR_THREADS
+#define RH_PAIR_THREADS 512
+#endif
+constexpr int kPairThreads = RH_PAIR_THREADS;
 template <bool kPerClass>
-__global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
+__global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
     const float4* __restrict__ cbox, const int4* __restrict__ cinfo,
     const float4* __restrict__ csum, const int* __restrict__ counters,
     const int* __restrict__ list_len, int batch, u64* __restrict__ mask, u64* __restrict__ nz,
@@ -1620,7 +1624,7 @@ __global__ __launch_bounds__(kThreads) void nms_pairs_kernel(
   const float area = me.area;
   const bool valid = me.rank >= 0;
   const u64 lanes_ok = __ballot(valid);
-  const int nwaves = slices * (kThreads / 64), mywave = slice * (kThreads / 64) + wave;
+  const int nwaves = slices * (kPairThreads / 64), mywave = slice * (kPairThreads / 64) + wave;
 
   // lanes of `mine` that may overlap box b (record info) by more than thresh (almost always
   // none).  The box is wave-uniform and sits in scalar registers.
@@ -2305,23 +2309,29 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
                          w.slabel, keff, w.csum, w.cinfo, w.mask, p.box_cap, p.wstride, p.clusters);
       RH_CHECK_LAUNCH("cluster_prepare_kernel");
     }
-    // `slices` blocks (4 waves each) share the cluster pairs of one cluster (the bench workload
+    // `slices` blocks (kPairThreads / 64 waves each) share the cluster pairs of one cluster (the bench workload
     // above with 1 / 2 / 4 / 8 slices: 96.0 / 93.3 / 95.9 / 99.7 us per call)
     int slices = 1;                                   // a power of two (the kernel masks with it)
     while (slices < 8 && slices * 64 <= p.clusters) slices *= 2;
+    slices = std::max(1, slices * kThreads / kPairThreads);
     RH_REQUIRE((long long)p.clusters * slices * p.batch < (1ll << 31), RH_ESHAPE, "too many NMS workgroups");
     auto kern = per_class ? nms_pairs_kernel<true> : nms_pairs_kernel<false>;
     // Blocks per image: enough for three quarters of the list capacity at one unit (cluster,
     // slice) each; the blocks of a longer list take a second unit.  Lists are mostly well below
     // the capacity, and blocks that find no unit still cost their dispatch, above all while other
-    // batches' kernels are being dispatched too (608 px, 16 images, about 2 000 of 4 096 candidates,
-    // whole call on one stream / three batches in flight: all units 93.4 / 68.4 us, three
-    // quarters 92.7 / 67.8, half 93.6 / 67.3, a quarter 97.5 / 70).
-    // (Only for grids of more than 1 024 blocks: for two images with full lists the second
+    // batches' kernels are being dispatched too.  608 px, 16 images, about 2 000 of 4 096
+    // candidates, whole call on one stream / three batches in flight, 4-wave blocks: all units
+    // 93.4 / 68.4 us, three quarters 92.7 / 67.8, half 93.6 / 67.3, a quarter 97.5 / 70; 8-wave
+    // blocks (half as many): all units 92.3 / 65.9, three quarters 92.4 / 65.5; 16-wave blocks
+    // 94.7 / 76.4.
+    // (Only for grids of more than 512 blocks: for two images with full lists the second
     // units cost the pair kernel 31 instead of 20 us.)
     const int all_units = p.clusters * slices;
-    const int units = (long long)all_units * p.batch > 1024 ? (all_units * 3 + 3) / 4 : all_units;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(units * p.batch)), dim3(kThreads), 0, s,
+#ifndef RH_PAIR_GRID_LIMIT
+#define RH_PAIR_GRID_LIMIT 512
+#endif
+    const int units = (long long)all_units * p.batch > RH_PAIR_GRID_LIMIT ? (all_units * 3 + 3) / 4 : all_units;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(units * p.batch)), dim3(kPairThreads), 0, s,
                        p.ranked ? w.cbox : w.sbox, w.cinfo, w.csum, w.counters,
                        p.select ? w.sel_count : w.counters, p.batch, w.mask, w.nz,
                        p.cap, p.ranked ? p.cap : p.box_cap, p.clusters, p.box_cap, p.wstride, p.nzw,
