@@ -195,7 +195,9 @@ __device__ __forceinline__ void emit_tile(const int tile, const int rows, const 
 // At most four waves per SIMD: with the eight its register count allows, the kernel is slower
 // (54.3 against 50.9 us) -- more tiles in flight than the memory system turns over in order.
 // One tile per workgroup: with 2 / 4 / 8 consecutive tiles each (fewer workgroups to dispatch) the
-// whole post-processing call takes 92.8 / 95.5 / 101.5 instead of 91.2 us.
+// whole post-processing call takes 92.8 / 95.5 / 101.5 instead of 91.2 us.  With 2 / 4 tiles side by side in
+// workgroups of 8 / 16 waves: 91.5 / 89.9 against 91.0 us per call, but 66.4 / 67.8 against 65.8 us
+// per batch with three batches in flight.
 template <int U, bool kLogits>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 4))) void score_scan_tile_kernel(
     const float* __restrict__ prob, TileCands tc, int C, int total_rows, unsigned magic_c,
