@@ -913,7 +913,10 @@ constexpr int kRankKeys = 64 * kRankKpl;
 // first pass's anchors and regressions before the bucketing (with barriers that do not wait for
 // global loads) changed nothing.
 constexpr int kRankKplMax = RH_RANK_KPL_MAX;
-constexpr int kRankThreads = 512;
+#ifndef RH_RANK_THREADS
+#define RH_RANK_THREADS 512
+#endif
+constexpr int kRankThreads = RH_RANK_THREADS;
 constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankBatch = 3;   // groups of 64 tiles whose lists a wave loads together
 #ifndef RH_RANK_SLOTS
@@ -1312,9 +1315,10 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   unsigned short* b_idx = reinterpret_cast<unsigned short*>(s_dyn + 3 * rank_lds_keys(cap));
   {
     const int limit = max(64, K >> 3);      // a fuller bin: counting over the whole list is cheaper
-    int h[2], incl[2];
+    constexpr int kRounds = (kSelBins / 64 + kRankWaves - 1) / kRankWaves;
+    int h[kRounds], incl[kRounds];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kRounds; ++u) {
       const int ch = wave + u * kRankWaves;                       // 64 bins, from the top
       h[u] = ch < kSelBins / 64 ? s_cursor[kSelBins - 1 - (ch * 64 + lane)] : 0;
       incl[u] = h[u];
@@ -1328,7 +1332,7 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kRounds; ++u) {
       const int ch = wave + u * kRankWaves;
       if (ch < kSelBins / 64) {
         int off = 0;
