@@ -49,7 +49,7 @@ class PostprocessPipeline:
     per process: a fourth stream gains 2 % when the queues fall well and loses 5-10 % when two
     streams share one, which is not under the caller's control.  Twice as many slots keep the
     streams fed while the host waits for the oldest batch (608 px, 80 classes, 16 images:
-    75 us per batch with three slots, 67-68 with six; 92 one batch at a time).
+    79 us per batch with three slots, 67 with six (an occasional run 74); 92 one batch at a time).
     The remaining keyword arguments are those of ``retinahead.postprocess`` (``score_thresh``,
     ``iou_thresh``, ``mode``, ``pre_nms_topk``, ``max_det``, ``max_candidates``, ``from_logits``).
 
