@@ -2329,7 +2329,7 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
     // candidates, whole call on one stream / three batches in flight, 4-wave blocks: all units
     // 93.4 / 68.4 us, three quarters 92.7 / 67.8, half 93.6 / 67.3, a quarter 97.5 / 70; 8-wave
     // blocks (half as many): all units 92.3 / 65.9, three quarters 92.4 / 65.5; 16-wave blocks
-    // 94.7 / 76.4.
+    // 94.7 / 76.4; two 8-wave blocks per cluster 94.4 / 68-72.
     // (Only for grids of more than 512 blocks: for two images with full lists the second
     // units cost the pair kernel 31 instead of 20 us.)
     const int all_units = p.clusters * slices;
