@@ -842,7 +842,7 @@ def rand_dets(seed, k, size=200.0, cluster=True):
     return boxes, scores
 
 
-@pytest.mark.parametrize("k", [1, 2, 63, 64, 65, 500, 2000, 5000])
+@pytest.mark.parametrize("k", [1, 2, 63, 64, 65, 500, 2000, 5000, 8192, 8193])
 def test_nms_vs_oracle(rh, k):
     boxes, scores = rand_dets(k, k)
     scores[: k // 3] = scores[k // 3: 2 * (k // 3)]      # score ties: lower index first
