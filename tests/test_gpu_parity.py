@@ -1082,6 +1082,18 @@ def test_sigmoid_and_postprocess_on_logits(rh):
     assert np.array_equal(res["boxes"].cpu().numpy(), bo)
 
 
+def test_postprocess_many_images_with_long_lists(rh):
+    """More images than a sixth of the compute units, each with a few thousand candidates: the
+    rank sort gives an image only a handful of workgroups, which then take several clusters of 64
+    list entries each, in more than one pass; lists longer than three quarters of the room make
+    the pair kernel's workgroups take a second unit."""
+    cls, reg, anc = infer_batch(31, 44, 192, 8, mu=-4.6)
+    found = (cls.max(axis=2) > 0.05).sum(axis=1)
+    assert found.min() > 1500 and found.max() < 4096, found
+    check_post(rh, cls, reg, anc, 192)
+    check_post(rh, cls[:3], reg[:3], anc, 192, max_candidates=int(found[:3].max()))   # room met exactly
+
+
 def test_postprocess_per_class_topk_maxdet(rh):
     cls, reg, anc = infer_batch(2, 2, 192, 13, mu=-4.0)
     check_post(rh, cls, reg, anc, 192, mode="per_class")
