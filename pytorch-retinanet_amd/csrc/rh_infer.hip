@@ -991,6 +991,11 @@ __device__ __forceinline__ int rank_bin(const unsigned score_key) {
   return min(max(b, 0), kSelBins - 1);
 }
 
+// (Measured and left as it is: zeroing the first pass's predecessor words before the bins are laid
+// out, and requesting an entry's anchor and regression before the comparisons inside its bin --
+// the whole call stays at 92.4 us.  Of a block's 11 us, 1.8 are the counting pass, 4.0 the
+// gather, 1.1 laying out the bins, 0.5 filling them, 0.9 zeroing the words, 2.7 the ranks, boxes
+// and stores.)
 // One pass of a rank-sort block: counts the ranks of the NC clusters [c0, c0 + NC) of image j's
 // list (in LDS: s_sk, s_ix, s_lab; K entries) and writes what the NMS stage reads for them.
 template <int NC>
@@ -1345,11 +1350,13 @@ __global__ __launch_bounds__(kRankThreads) void sort_rank_kernel(int* __restrict
   }
   const bool bucketed = s_big == 0;
   __syncthreads();
+  RH_TL(0, 5);
   if (bucketed) {
     for (int i = tid; i < K; i += kRankThreads)
       b_idx[atomicAdd(&s_cursor[rank_bin(s_sk[i])], 1)] = (unsigned short)i;
     __syncthreads();
   }
+  RH_TL(0, 6);
   const RankBuckets bk{s_start, s_cursor, b_idx, bucketed};
   const int kpl = clusters_per_block(K);
   const int c_end = min(((int)blockIdx.y + 1) * kpl, (K + 63) >> 6);

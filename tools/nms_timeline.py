@@ -20,7 +20,7 @@ import bench  # noqa: E402
 import retinahead as rh  # noqa: E402
 from retinahead import functional as F  # noqa: E402
 
-KERNELS = {0: ("sort_rank", ["start", "count pass", "list in LDS", "ranks counted", "end"]),
+KERNELS = {0: ("sort_rank", ["start", "count pass", "list in LDS", "ranks counted", "end", "bins laid out", "bins filled"]),
            1: ("nms_pairs", ["start", "counters read", "own cluster loaded", "end"]),
            2: ("nms_resolve", ["start", "words loaded", "rounds done", "end", "round 1 done", None,
                                "round 2 done", "round 3 done"])}
