@@ -10,11 +10,11 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import REG_ATOL_REL, RTOL, grad_close
 from oracle import dense_head_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-5
 
 # (name, batch, image size, classes, padded GT rows, valid GT rows per image)
 CONFIGS = {
@@ -75,13 +75,9 @@ def test_loss_full_size(rh, name):
     assert num_pos[j] == ref["num_pos"][0]
     assert np.isclose(per_image[0, j], ref["cls_per_image"][0], rtol=RTOL)
     assert np.isclose(per_image[1, j], ref["reg_per_image"][0], rtol=RTOL)
-    want = ref["d_classifications"][0].astype(np.float64)
-    got = d_cls[j].cpu().numpy().astype(np.float64)
-    assert (np.abs(got - want) <= RTOL * np.abs(want) + 1e-7 * np.abs(want).max()).all()
-    assert np.array_equal(got == 0, want == 0)
-    want = ref["d_regressions"][0].astype(np.float64)
-    got = d_reg[j].cpu().numpy().astype(np.float64)
-    assert (np.abs(got - want) <= RTOL * np.abs(want) + 4e-6 * np.abs(want).max()).all()
+    # the suite's one gradient bar: no floor for dL/dp, REG_ATOL_REL of the largest for dL/dr
+    grad_close(d_cls[j].cpu().numpy(), ref["d_classifications"][0])
+    grad_close(d_reg[j].cpu().numpy(), ref["d_regressions"][0], atol_rel=REG_ATOL_REL, kind="d_reg")
 
     # (b) batch mean of the per-image losses (losses.py:139-141)
     assert np.allclose(losses, per_image.mean(axis=1), rtol=1e-6)

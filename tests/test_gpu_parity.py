@@ -9,21 +9,10 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, logits_grad_close
+from conftest import FLOOR_STATS, REG_ATOL_REL, RTOL, grad_close, load_golden, logits_grad_close
 from oracle import dense_head_oracle as O
 
 pytestmark = pytest.mark.gpu
-
-RTOL = 1e-5
-# Regression gradients: inside the quadratic zone of smooth-L1 the gradient is 9*(t - r), so a
-# one-ulp difference of log() in the target t (|t| up to a few units) moves it by 9*ulp(t) however
-# small t - r is: a floor any float32 evaluation has.  Measured over every regression-gradient
-# comparison of this file (1.45 M elements, 45 396 of them non-zero): 41 elements pass only thanks
-# to the floor, the largest excess being 1.02e-6 of the largest gradient (the linear zone's +-1);
-# the floor is set to twice that.  Among elements above 1e-3 of the largest gradient the worst
-# purely relative error is 2.0e-4 (one of those quadratic-zone elements).  Classification
-# gradients need no floor at all (31 M elements, worst relative error 3.9e-7): theirs is 0.
-REG_ATOL_REL = 2e-6
 
 
 @pytest.fixture(scope="module")
@@ -36,35 +25,6 @@ def rh():
 
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
-
-
-# What the absolute floors of grad_close actually did, per kind of gradient: filled as the tests
-# run, checked and written out by test_zz_tolerance_floors_report at the end of this file.
-FLOOR_STATS = {}
-
-
-def grad_close(got, want, rtol=RTOL, atol_rel=0.0, kind="d_cls"):
-    want = np.asarray(want, np.float64)
-    got = np.asarray(got, np.float64)
-    top = float(np.max(np.abs(want))) if want.size else 0.0
-    err = np.abs(got - want)
-    bad = err > rtol * np.abs(want) + atol_rel * top
-    assert not bad.any(), f"{bad.sum()} of {bad.size} elements off; worst abs {np.max(err)}"
-    assert np.array_equal(got == 0, want == 0)
-    if want.size and top > 0:
-        over = err > rtol * np.abs(want)              # these pass only thanks to the absolute floor
-        big = np.abs(want) > 1e-3 * top
-        st = FLOOR_STATS.setdefault(kind, dict(elements=0, nonzero=0, needed_floor=0, floor_used_rel=0.0,
-                                               worst_rel_above_milli_max=0.0))
-        st["elements"] += int(want.size)
-        st["nonzero"] += int(np.count_nonzero(want))
-        st["needed_floor"] += int(over.sum())
-        if over.any():
-            st["floor_used_rel"] = max(st["floor_used_rel"],
-                                       float(np.max(err[over] - rtol * np.abs(want[over])) / top))
-        if big.any():
-            st["worst_rel_above_milli_max"] = max(st["worst_rel_above_milli_max"],
-                                                    float(np.max(err[big] / np.abs(want[big]))))
 
 
 # ------------------------------------------------------------------ anchors
@@ -1228,7 +1188,8 @@ def test_two_host_threads_on_their_own_streams(rh):
 
 
 def test_zz_tolerance_floors_report(rh):
-    """Runs after the gradient tests of this file (name order) and states what their absolute
+    """Runs after the gradient tests of this file, of the full-size configurations and of the
+    two-rank runs (file and name order) and states what their absolute
     floors were needed for: how many elements passed only thanks to a floor, how much of the
     floor was used, and the worst purely relative error among elements above 1e-3 of the largest
     gradient.  The numbers go to gpurun_out/tolerance_floors.json."""
