@@ -143,6 +143,81 @@ def cpu_baseline_post(cls, reg, anc, size, sample_images, threads, budget_s):
     return sample_images / best, best
 
 
+class RankExchange:
+    """The one exchange of a data-parallel step: the all-reduce of the 4-float vector (loss sums,
+    positive anchors, images) that each rank's launch leaves behind.  RCCL: asynchronous, with a
+    bounded backlog; rehearsal backends (gloo): blocking, through the host."""
+
+    def __init__(self, world, backend):
+        import torch.distributed as dist
+        self.dist, self.world, self.backend, self.pending, self.last = dist, world, backend, [], None
+
+    def submit(self, vec):
+        if self.world <= 1:
+            return
+        vec = vec.clone()                    # a graph replay rewrites its own copy every step
+        if self.backend == "nccl":
+            self.pending.append((vec, self.dist.all_reduce(vec, op=self.dist.ReduceOp.SUM, async_op=True)))
+            if len(self.pending) > 4:        # bounded backlog; values are the global losses
+                self.last = self.pending[0][0]
+                self.pending.pop(0)[1].wait()
+        else:
+            host = vec.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)
+            self.last = host
+
+    def fence(self, sync):
+        """Everything issued so far is done on every rank: drain, synchronise, barrier, synchronise."""
+        while self.pending:
+            self.last = self.pending[0][0]
+            self.pending.pop(0)[1].wait()
+        sync()
+        if self.world > 1:
+            self.dist.barrier()
+        sync()
+
+
+def count_ranks(world, backend, dev):
+    """How many ranks take part, by an all-reduce of ones."""
+    if world <= 1:
+        return 1
+    import torch.distributed as dist
+    ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    return int(ones.item())
+
+
+def timed_blocks(step, exchange, sync, steps, warmup, repeats, world, backend, dev):
+    """`warmup` untimed steps, then `repeats` blocks of exactly `steps` steps, each block between
+    two fences; returns the block times in seconds, per block the slowest rank."""
+    for _ in range(warmup):
+        step()
+    exchange.fence(sync)
+    blocks = []
+    for _ in range(max(repeats, 1)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        exchange.fence(sync)
+        blocks.append(time.perf_counter() - t0)
+    blocks = torch.tensor(blocks, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        t = blocks.to(dev) if backend == "nccl" else blocks
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blocks = t.cpu()
+    return blocks.numpy()
+
+
+def require_ranks(ranks_seen, gpus, devices, backend):
+    """A scaling run must be what it says: one rank per GPU, all of them there."""
+    if ranks_seen != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but the all-reduce saw {ranks_seen} ranks")
+    if gpus > 1 and backend == "nccl" and devices < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but this node shows {devices} GPU(s): ranks would "
+                         "share a card (RH_BENCH_BACKEND=gloo rehearses that on purpose)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +242,11 @@ def main():
     # one rank per GPU; RH_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the
     # multi-rank path on a one-GPU box (RCCL refuses two ranks on the same device)
     backend = os.environ.get("RH_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    devices = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and devices < world:
+        raise SystemExit(f"bench.py: --gpus {world} but this node shows {devices} GPU(s): ranks would "
+                         "share a card (RH_BENCH_BACKEND=gloo rehearses that on purpose)")
+    dev_index = local_rank % max(devices, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -190,173 +269,150 @@ def main():
     n = anchors.shape[1]
     rng = np.random.default_rng(2000 + rank)
     cls_np, reg_np, ann_np = synth_train(rng, BATCH, n, CLASSES, SIZE, MAX_GT)
-    cls = torch.from_numpy(cls_np).to(dev).requires_grad_(True)
-    reg = torch.from_numpy(reg_np).to(dev).requires_grad_(True)
     ann = torch.from_numpy(ann_np).to(dev)
-
-    # Each rank's losses and gradients are scaled by 1/B_global inside the kernels
-    # (batch_divisor); the only exchange is the all-reduce of a 4-float vector (loss sums,
-    # positive anchors, images).
-    loss_mod = rh.FocalLoss(batch_divisor=BATCH * world)
+    # Two sets of predictions that take turns (a training loop never streams the same 355 MB
+    # twice in a row): the second set is the first with its images rotated by one, so that the
+    # numbers of the CPU leg below, which are for set 0, stay what they were.
+    cls_sets = [torch.from_numpy(cls_np).to(dev)]
+    reg_sets = [torch.from_numpy(reg_np).to(dev)]
+    cls_sets.append(torch.roll(cls_sets[0], 1, 0).contiguous())
+    reg_sets.append(torch.roll(reg_sets[0], 1, 0).contiguous())
+    for t in cls_sets + reg_sets:
+        t.requires_grad_(True)
+    cls, reg = cls_sets[0], reg_sets[0]
 
     prefetch = not args.no_prefetch
+    sync = lambda: torch.cuda.synchronize(dev)
 
-    def local_step():
-        cls.grad = None
-        reg.grad = None
-        if prefetch:
-            # the NEXT step's IoU assignment (it needs the annotations only, which a loader has
-            # ahead of time; here every batch carries the same ones) rides on this step's
-            # [B,N,C] stream launch; this step uses the assignment the previous step carried.
-            # One assignment per step either way.
-            loss_mod.prefetch_assignment(anchors, ann, CLASSES)
-        out = loss_mod(cls, reg, anchors, ann)
-        loss = sum(l for l in out.values())      # train.py:185
-        loss.backward()                          # train.py:190
-        if world > 1:
+    def make_runner(n_sets, eager=False, announce=prefetch):
+        """A step() that runs the module's forward + backward on input set (step index % n_sets).
+
+        The step is a handful of kernels (~130 us of GPU work), which eager PyTorch cannot enqueue
+        fast enough (autograd + dispatcher cost ~160 us of host time per step): forward + backward
+        are captured into hipGraphs and replayed.  Two graphs take turns: with the assignment
+        running ahead there are two workspaces in turn (A: step on workspace X, next assignment
+        into Y; B: the reverse), and graph k reads input set k % n_sets."""
+        # Each rank's losses and gradients are scaled by 1/B_global inside the kernels
+        # (batch_divisor); the only exchange is the all-reduce of a 4-float vector (loss sums,
+        # positive anchors, images).
+        mod = rh.FocalLoss(batch_divisor=BATCH * world)
+
+        def local_step(k):
+            c, r = cls_sets[k % n_sets], reg_sets[k % n_sets]
+            c.grad = None
+            r.grad = None
+            if announce:
+                # the NEXT step's IoU assignment (it needs the annotations only, which a loader has
+                # ahead of time; here every batch carries the same ones) rides on this step's
+                # [B,N,C] stream launch; this step uses the assignment the previous step carried.
+                # One assignment per step either way.
+                mod.prefetch_assignment(anchors, ann, CLASSES)
+            out = mod(c, r, anchors, ann)
+            loss = sum(l for l in out.values())      # train.py:185
+            loss.backward()                          # train.py:190
             # what the ranks exchange: loss sums, positive anchors, images (one 16-byte
-            # all-reduce); the finalize kernel leaves the four floats side by side
+            # all-reduce); the finalize stage leaves the four floats side by side
             out = dict(out)
-            out["exchange"] = loss_mod.last["exchange"]
-        return out
+            out["exchange"] = mod.last["exchange"]
+            return out
 
-    # The step is a handful of kernels (~140 us of GPU work), which eager PyTorch cannot
-    # enqueue fast enough (autograd + dispatcher cost ~160 us of host time per step): capture
-    # the module's forward + backward into hipGraphs and replay them.  With the assignment
-    # running ahead there are two workspaces in turn, hence two graphs replayed alternately
-    # (A: step on workspace X, next assignment into Y; B: the reverse).  --eager times the
-    # plain Python path instead.
-    launch = "eager"
-    graphs = []
-    static_outs = []
-    if not args.eager:
-        try:
-            side = torch.cuda.Stream(device=dev)
+        side = torch.cuda.Stream(device=dev)
+        graphs, outs = [], []
+        if not eager:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                for _ in range(4):
-                    local_step()
+                for k in range(4):
+                    local_step(k)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize()
-            cls.grad = None
-            reg.grad = None
-            for _ in range(2 if prefetch else 1):
+            for k in range(2):
                 g = torch.cuda.CUDAGraph()
                 # thread_local: calls made meanwhile by other threads of the process (the
                 # collective library's watchdog polls events) cannot invalidate the capture
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    static_outs.append(local_step())
+                    outs.append(local_step(k))
                 graphs.append(g)
-            launch = ("hipGraph replay of FocalLoss forward + backward"
-                      + (", next step's assignment inside the stream launch (2 graphs in turn)"
-                         if prefetch else ""))
-        except Exception as e:                   # pragma: no cover - depends on the runtime
-            print(f"[bench] graph capture failed ({e!r}); timing the eager path", file=sys.stderr)
-            graphs = []
-            torch.cuda.synchronize()
+        turn = [0]
 
-    pending = []
-    turn = [0]
-
-    def step():
-        if graphs:
-            k = turn[0] % len(graphs)
+        def step():
+            k = turn[0]
             turn[0] += 1
-            graphs[k].replay()
-            out = static_outs[k]
-        else:
-            out = local_step()
-        if world > 1:
-            vec = out["exchange"].clone()        # the replay rewrites its own copy every step
-            if backend == "nccl":
-                pending.append((vec, dist.all_reduce(vec, op=dist.ReduceOp.SUM, async_op=True)))
-                if len(pending) > 4:             # bounded backlog; values are the global losses
-                    pending.pop(0)[1].wait()
-            else:                                # rehearsal backends: blocking, through the host
-                host = vec.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        return out
+            if graphs:
+                graphs[k % 2].replay()
+                out = outs[k % 2]
+            else:
+                out = local_step(k)
+            exchange.submit(out["exchange"])
+            return out
+        step.local_step, step.side, step.graphs = local_step, side, graphs
+        return step
 
-    def fence():
-        while pending:
-            pending.pop(0)[1].wait()
-        torch.cuda.synchronize()
+    exchange = RankExchange(world, backend)
+    launch = "eager"
+    try:
+        step = make_runner(2, eager=args.eager)
+        if step.graphs:
+            launch = ("hipGraph replay of FocalLoss forward + backward"
+                      + (", next step's assignment inside the stream launch" if prefetch else "")
+                      + "; two graphs in turn, each on its own set of predictions")
+    except Exception as e:                       # pragma: no cover - depends on the runtime
         if world > 1:
-            dist.barrier()
+            raise
+        print(f"[bench] graph capture failed ({e!r}); timing the eager path", file=sys.stderr)
         torch.cuda.synchronize()
+        step = make_runner(2, eager=True)
 
-    ranks_seen = 1
-    if world > 1:
-        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        ranks_seen = int(ones.item())
+    ranks_seen = count_ranks(world, backend, dev)
+    require_ranks(ranks_seen, args.gpus, devices, backend)
 
     note(f"launch mode: {launch}")
-    for _ in range(args.warmup):
-        out = step()
-    note("warm-up enqueued")
-    fence()
-    note("warm-up done")
-    blocks = []
-    for _ in range(max(args.repeats, 1)):
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        fence()
-        blocks.append(time.perf_counter() - t0)
+    blocks = timed_blocks(step, exchange, sync, args.steps, args.warmup, args.repeats, world, backend, dev)
     note(f"timed blocks done: median {np.median(blocks):.5f} s")
-    blocks = torch.tensor(blocks, dtype=torch.float64)
-    if world > 1:
-        t = blocks.to(dev) if backend == "nccl" else blocks
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # per block, the slowest rank
-        blocks = t.cpu()
-    blocks = blocks.numpy()
     elapsed = float(np.median(blocks))
     block_p10, block_p90 = (float(np.percentile(blocks, q)) for q in (10, 90))
     anchors_per_s = world * BATCH * n * args.steps / elapsed
 
-    # eager path beside it (rank-local, short), for the record
-    eager_ms = None
-    if graphs:
-        with torch.cuda.stream(side):        # the stream the tensors' autograd nodes were made on
-            for _ in range(5):
-                local_step()
+    def replay_ms(fn, per_call=1):
+        """Median milliseconds per step of fn() replayed back to back (rank-local, short)."""
+        times = []
+        for _ in range(12):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(50):
-                local_step()
+            for _ in range(max(args.steps // per_call, 1)):
+                fn()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t1) / (per_call * max(args.steps // per_call, 1)) * 1e3)
+        return float(np.median(times[2:]))
+
+    # the same with ONE set of predictions streamed every step (what this benchmark measured
+    # before): beside the headline so that any help from the caches shows
+    same_input_ms = None
+    if step.graphs and world == 1:
+        try:
+            one = make_runner(1)
+            same_input_ms = replay_ms(one)
+        except Exception as e:                   # pragma: no cover
+            print(f"[bench] single-input graphs failed ({e!r})", file=sys.stderr)
+
+    # eager path beside it (rank-local, short), for the record
+    eager_ms = None
+    if step.graphs:
+        with torch.cuda.stream(step.side):        # the stream the tensors' autograd nodes were made on
+            for k in range(5):
+                step.local_step(k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(50):
+                step.local_step(k)
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t1) / 50 * 1e3
 
     # the same step with every assignment in a launch of its own (no announcement of the next
-    # batch's annotations), replayed from one graph: what a loop that cannot look ahead gets
+    # batch's annotations): what a loop that cannot look ahead gets
     plain_ms = None
-    if graphs and prefetch:
+    if step.graphs and prefetch and world == 1:
         try:
-            plain_mod = rh.FocalLoss(batch_divisor=BATCH * world)
-            def plain_step():
-                cls.grad = None
-                reg.grad = None
-                out = plain_mod(cls, reg, anchors, ann)
-                sum(l for l in out.values()).backward()
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    plain_step()
-            torch.cuda.synchronize()
-            cls.grad = None
-            reg.grad = None
-            pg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(pg, stream=side, capture_error_mode="thread_local"):
-                plain_step()
-            times = []
-            for _ in range(12):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    pg.replay()
-                torch.cuda.synchronize()
-                times.append((time.perf_counter() - t1) / args.steps * 1e3)
-            plain_ms = float(np.median(times[2:]))
+            plain_ms = replay_ms(make_runner(2, announce=False))
         except Exception as e:                   # pragma: no cover - depends on the runtime
             print(f"[bench] plain-step graph failed ({e!r})", file=sys.stderr)
 
@@ -364,23 +420,15 @@ def main():
     # idles about 8 us (the marker that ends a launch), inside a graph the next kernel starts when
     # the previous one ends -- what the path costs inside a training iteration captured whole
     pair_ms = None
-    if graphs and prefetch and world == 1:
+    if step.graphs and prefetch and world == 1:
         try:
-            cls.grad = None
-            reg.grad = None
+            for t in cls_sets + reg_sets:
+                t.grad = None
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
-                local_step()
-                local_step()
-            times = []
-            for _ in range(12):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(max(args.steps // 2, 1)):
-                    g2.replay()
-                torch.cuda.synchronize()
-                times.append((time.perf_counter() - t1) / (2 * max(args.steps // 2, 1)) * 1e3)
-            pair_ms = float(np.median(times[2:]))
+            with torch.cuda.graph(g2, stream=step.side, capture_error_mode="thread_local"):
+                step.local_step(0)
+                step.local_step(1)
+            pair_ms = replay_ms(g2.replay, per_call=2)
         except Exception as e:                   # pragma: no cover - depends on the runtime
             print(f"[bench] two-step graph failed ({e!r})", file=sys.stderr)
 
@@ -395,29 +443,35 @@ def main():
 
     # ---- roofline of the dominant kernel: the N x C stream -----------------------------------
     with torch.no_grad():
-        bufs = F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann)   # fills the workspace
-        stream_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann,
-                                                 stages=_lib.STAGE_STREAM, out=bufs)
+        det = [(c.detach(), r.detach()) for c, r in zip(cls_sets, reg_sets)]
+        bufs = F.focal_loss_fwd_bwd(det[0][0], det[0][1], anchors, ann)   # fills the workspace
+        flip = [0]
+
+        def stream_fn(**kw):
+            # consecutive launches take the two sets of predictions in turn (same annotations, so
+            # the workspace's assignment serves both)
+            c, r = det[flip[0] % 2]
+            flip[0] += 1
+            return F.focal_loss_fwd_bwd(c, r, anchors, ann, stages=_lib.STAGE_STREAM, out=bufs, **kw)
         for _ in range(10):
             stream_fn()
         k1_mean, k1_min = event_times(stream_fn, 100)
         plain_mean, plain_min = event_train(stream_fn, 20, 10)
+        carried_fn = stream_fn
         if prefetch:
             # the launch as the timed steps issue it: with the next step's assignment workgroups
             # at the end of its grid
             next_ws = F.focal_workspace(BATCH, n, CLASSES, ann.shape[1], dev)
             next_out = F.new_small_outputs(BATCH, dev)
-            stream_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann,
-                                                     stages=_lib.STAGE_STREAM, out=bufs,
-                                                     ahead=(ann, next_ws, next_out))
+            carried_fn = lambda: stream_fn(ahead=(ann, next_ws, next_out))
             for _ in range(10):
-                stream_fn()
-        k_mean, k_min = event_train(stream_fn, 20, 10)
+                carried_fn()
+        k_mean, k_min = event_train(carried_fn, 20, 10)
         k_p10, k_p50, k_p90 = (float(np.percentile(event_train.last, q)) for q in (10, 50, 90))
-        assign_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann,
+        assign_fn = lambda: F.focal_loss_fwd_bwd(det[0][0], det[0][1], anchors, ann,
                                                  stages=_lib.STAGE_ASSIGN, out=bufs)
         a_mean, _ = event_times(assign_fn, 50)
-        all_fn = lambda: F.focal_loss_fwd_bwd(cls.detach(), reg.detach(), anchors, ann, out=bufs)
+        all_fn = lambda: F.focal_loss_fwd_bwd(det[0][0], det[0][1], anchors, ann, out=bufs)
         f_mean, _ = event_times(all_fn, 100)
     algo_bytes = BATCH * n * (8 * CLASSES + 48)
     achieved = algo_bytes / (k_mean * 1e-3) / 1e9
@@ -458,51 +512,101 @@ def main():
         del lg_bufs, lv_bufs, cls_lv, reg_lv, logits
 
     # ---- decode + NMS (second half of the metric) ------------------------------------------
+    # Input sets: every batch in flight has predictions of its own, and the single-stream loop
+    # takes two sets in turn -- a serving loop never reads the same 355 MB twice, and with one
+    # shared tensor a trailing scan could be fed from the caches by the one ahead of it.  The
+    # old figures on ONE shared tensor are measured beside them.
+    n_streams = args.post_streams
     icls_np, ireg_np = synth_infer(np.random.default_rng(3000), BATCH, n, CLASSES)
-    icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
-    post = lambda out=None: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, cand_cap=4096, out=out)
+    n_sets = max(n_streams + 1, 2)
+    icls_sets = [torch.from_numpy(icls_np).to(dev)]
+    ireg_sets = [torch.from_numpy(ireg_np).to(dev)]
+    for k in range(1, n_sets):          # the same images in another order: same work per batch
+        icls_sets.append(torch.roll(icls_sets[0], k, 0).contiguous())
+        ireg_sets.append(torch.roll(ireg_sets[0], k, 0).contiguous())
+    icls, ireg = icls_sets[0], ireg_sets[0]
+
+    def post_on(k):
+        c, r = icls_sets[k % n_sets], ireg_sets[k % n_sets]
+        return lambda out=None: F.postprocess_raw(c, r, anchors, SIZE, SIZE, cand_cap=4096, out=out)
+    post = post_on(0)
     res = post()
     counts = res["counts"].cpu().numpy()
     for _ in range(5):
         post(res)
     p_mean, p_min = event_times(lambda: post(res), 200)
     event_times.last_post = list(event_times.last)
-    # batches back to back on ONE stream, by the host clock over 300 batches (an event pair around
-    # every call adds a few microseconds of its own to these four short kernels)
-    singles = []
-    for _ in range(5):
-        for _ in range(50):
-            post(res)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(300):
-            post(res)
-        torch.cuda.synchronize()
-        singles.append((time.perf_counter() - t1) / 300 * 1e3)
-    single_ms = float(np.median(singles))
+
+    def single_stream(fns, batches=300):
+        """ms per batch, batches issued back to back on ONE stream by the host clock (an event pair
+        around every call adds a few microseconds of its own to these short kernels), the calls
+        taking the given input sets in turn; median of 5 runs and the runs."""
+        runs = []
+        for _ in range(5):
+            for i in range(50):
+                fns[i % len(fns)](res)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(batches):
+                fns[i % len(fns)](res)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t1) / batches * 1e3)
+        return float(np.median(runs)), runs
+    single_ms, singles = single_stream([post_on(0), post_on(1)])
+    single_same_ms, _ = single_stream([post])
     d_mean, _ = event_times(lambda: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, cand_cap=4096,
                                                       stages=_lib.POST_DECODE, out=res), 50)
     decode_bytes = BATCH * n * (4 * CLASSES + 32)
-    # Batches in flight on separate streams (each with its own workspace and outputs): the score
-    # scan is bound by HBM, the rank sort, the pair search and the resolve rounds by latency, so
-    # consecutive batches overlap well.
+
+    # One image, one stream: the call shape of the reference's inference scripts
+    # (visualize.py:95, evaluate.py:95, csv_eval.py:89, coco_eval.py:27).  Latency of the whole
+    # post-processing call as the GPU sees it (calls issued back to back on one stream: each
+    # call's kernels depend on one another, so time per call = the chain's latency), and as a host
+    # sees it (call + synchronize).  Two images take turns.
+    one_fns = [(lambda c, r: (lambda out=None: F.postprocess_raw(c, r, anchors, SIZE, SIZE, cand_cap=4096,
+                                                                 out=out)))(icls_sets[k][:1].contiguous(),
+                                                                            ireg_sets[k][:1].contiguous())
+               for k in range(2)]
+    res1 = one_fns[0]()
+    b1_runs = []
+    for _ in range(6):
+        for i in range(20):
+            one_fns[i % 2](res1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(200):
+            one_fns[i % 2](res1)
+        torch.cuda.synchronize()
+        b1_runs.append((time.perf_counter() - t1) / 200 * 1e6)
+    b1_latency_us = float(np.median(b1_runs[1:]))
+    b1_sync = []
+    for i in range(220):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_fns[i % 2](res1)
+        torch.cuda.synchronize()
+        b1_sync.append((time.perf_counter() - t1) * 1e6)
+    b1_sync_us = float(np.median(b1_sync[20:]))
+    b1_kept = int(res1["counts"][0, 0])
+
+    # Batches in flight on separate streams (each with its own inputs, workspace and outputs): the
+    # score scan is bound by HBM, the rank sort, the pair search and the resolve rounds by latency,
+    # so consecutive batches overlap well.
     # HIP multiplexes streams onto a few hardware queues (4 per process here), and which queue a
-    # stream gets is not visible.  Three streams and the default stream have a queue each: fifteen
-    # trials in three processes all lay within 68.4-69.0 us per batch.  Four streams reach 67 us
-    # when the queues fall well and 72 or 76 when two of them share one, at random from one trial
-    # to the next (tools/stream_sets.py, tools/scan_chain.py; streams created directly, a larger
-    # GPU_MAX_HW_QUEUES or an event chain between the scans do not settle it), so three is the
+    # stream gets is not visible.  Three streams and the default stream have a queue each.  Four
+    # streams are faster when the queues fall well and slower when two of them share one, at random
+    # from one trial to the next (tools/stream_sets.py, tools/scan_chain.py), so three is the
     # default, and three trials with one stream more are listed beside it.
     # Five fresh sets of streams are measured in full; the reported rate is their median, and every
     # trial is listed.  (One more set runs first and is not counted: the first pipelined run of a
     # process is 10-15 us per batch slower whatever its streams, and is listed on its own.)
-    n_streams = args.post_streams
     stream_sets = [[torch.cuda.Stream(device=dev) for _ in range(n_streams)] for _ in range(6)]
     streams = stream_sets[0]
 
-    def piped(fn, rounds=100):
+    def piped(fn_of_slot, rounds=100):
+        fns = [fn_of_slot(i) for i in range(len(streams))]
         outs = []
-        for st in streams:
+        for st, fn in zip(streams, fns):
             st.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(st):
                 outs.append(fn())
@@ -511,7 +615,7 @@ def main():
 
         def run(k):
             for _ in range(k):
-                for st, o in zip(streams, outs):
+                for st, fn, o in zip(streams, fns, outs):
                     with torch.cuda.stream(st):
                         fn(o)
             torch.cuda.synchronize()
@@ -524,34 +628,42 @@ def main():
 
     p_med = float(np.median(event_times.last_post))
     streams = stream_sets[0]
-    warmup_trial = piped(post)
-    trial = []
+    warmup_trial = piped(post_on)
+    trial, trial_same = [], []
     for cand in stream_sets[1:]:
         streams = cand
-        trial.append(piped(post))
+        trial.append(piped(post_on))
+        trial_same.append(piped(lambda i: post, rounds=50))
     piped_ms = float(np.median(trial))
+    piped_same_ms = float(np.median(trial_same))
     trial_p10, trial_p90 = (float(np.percentile(trial, q)) for q in (10, 90))
     wider = []
     for _ in range(3):
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams + 1)]
-        wider.append(piped(post))
+        wider.append(piped(post_on))
     streams = stream_sets[1 + int(np.argsort(trial)[len(trial) // 2])]
-    # the same through the public helper (its host read of the counts per batch included)
-    pipe = rh.PostprocessPipeline(depth=2 * n_streams, streams=n_streams)
-    def pipe_run(k):
-        for _ in range(k):
-            if len(pipe) == 2 * n_streams:
+    # the same through the public helper (its host read of the counts per batch included); three
+    # fresh pipelines (each draws its own streams), the median is reported and all are listed
+    pipe_trials = []
+    for _ in range(3):
+        pipe = rh.PostprocessPipeline(depth=2 * n_streams, streams=n_streams)
+
+        def pipe_run(k):
+            for i in range(k):
+                if len(pipe) == 2 * n_streams:
+                    pipe.results()
+                pipe.submit(icls_sets[i % n_sets], ireg_sets[i % n_sets], anchors, (SIZE, SIZE))
+            while len(pipe):
                 pipe.results()
-            pipe.submit(icls, ireg, anchors, (SIZE, SIZE))
-        while len(pipe):
-            pipe.results()
-    pipe_run(100)
-    t1 = time.perf_counter()
-    pipe_run(400)
-    pipe_ms = (time.perf_counter() - t1) / 400 * 1e3
+        pipe_run(100)
+        t1 = time.perf_counter()
+        pipe_run(400)
+        pipe_trials.append((time.perf_counter() - t1) / 400 * 1e3)
+    pipe_ms = float(np.median(pipe_trials))
     # the same with only equal labels suppressing each other (batched per-class NMS)
-    per_class_ms = piped(lambda out=None: F.postprocess_raw(icls, ireg, anchors, SIZE, SIZE, per_class=True,
-                                                            cand_cap=4096, out=out), rounds=50)
+    per_class_ms = piped(lambda i: (lambda out=None: F.postprocess_raw(
+        icls_sets[i % n_sets], ireg_sets[i % n_sets], anchors, SIZE, SIZE, per_class=True,
+        cand_cap=4096, out=out)), rounds=50)
 
     line = {
         "metric": "focal_loss_fwd_bwd_anchors_per_sec",
@@ -576,7 +688,9 @@ def main():
                                "FocalLoss module forward + backward (fused kernels)",
                    "global_batch": BATCH * world, "parallelism": f"dp{world}", "launch": launch,
                    "eager_ms_per_step": eager_ms,
-                   "ms_per_step_without_announcing_the_next_batch": plain_ms, "ms_per_step_two_steps_per_graph": pair_ms},
+                   "ms_per_step_without_announcing_the_next_batch": plain_ms, "ms_per_step_two_steps_per_graph": pair_ms,
+                   "inputs": "two sets of predictions take turns (no step streams the tensor the step before it streamed)",
+                   "ms_per_step_one_input_set_every_step": same_input_ms},
         "parity_ok": parity,
         "roofline": {"bound": "hbm",
                      "kernel": "focal_stream_kernel<5, false, %s>" % ("true" if prefetch else "false")
@@ -588,7 +702,7 @@ def main():
                      "algorithmic_bytes": algo_bytes,
                      "kernel_ms_mean": k_mean, "kernel_ms_min": k_min,
                      "kernel_ms_p10_p50_p90": [k_p10, k_p50, k_p90],
-                     "timing": "HIP events around trains of 20 back-to-back launches, 10 trains",
+                     "timing": "HIP events around trains of 20 back-to-back launches (two sets of predictions in turn), 10 trains",
                      "stream_alone_kernel_ms_mean": plain_mean,
                      "stream_alone_frac": algo_bytes / (plain_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "single_launch_event_pair_ms_mean": k1_mean,
@@ -597,8 +711,10 @@ def main():
                        "stream_stage_from_logits": lg_mean,
                        "stream_stage_head_layout_from_logits": lv_mean},
         "decode_nms": {"images_per_s": BATCH / (piped_ms * 1e-3), "ms_per_batch": piped_ms,
-                       "launch": f"{n_streams} batches in flight on {n_streams} HIP streams; median of "
-                                 f"{len(trial)} stream sets, each measured over 400 batches",
+                       "launch": f"{n_streams} batches in flight on {n_streams} HIP streams, each with its own "
+                                 f"input tensors; median of {len(trial)} stream sets, each measured over "
+                                 f"{100 * n_streams} batches",
+                       "ms_per_batch_all_streams_reading_one_tensor": piped_same_ms,
                        "stream_set_trials_ms_per_batch": trial,
                        "uncounted_first_trial_ms_per_batch": warmup_trial,
                        "one_stream_more_trials_ms_per_batch": wider,
@@ -608,7 +724,15 @@ def main():
                        "single_stream_ms_per_batch": single_ms,
                        "single_stream_trials_ms_per_batch": singles,
                        "single_stream_frac_of_hbm_peak": decode_bytes / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "single_stream_timing": "host clock over 300 batches issued back to back on one stream, median of 5",
+                       "single_stream_timing": "host clock over 300 batches issued back to back on one stream, two "
+                                               "input sets in turn, median of 5",
+                       "single_stream_ms_per_batch_one_tensor_every_batch": single_same_ms,
+                       "b1_latency_us": b1_latency_us,
+                       "b1_latency_runs_us": b1_runs[1:],
+                       "b1_latency_timing": "one 608 px image per call, 200 calls back to back on one stream (two "
+                                            "images in turn), host clock over the run / 200; median of 5 runs",
+                       "b1_call_and_synchronize_us": b1_sync_us,
+                       "b1_kept": b1_kept,
                        "single_stream_event_pair_per_call_ms": {"median": p_med, "mean": p_mean, "min": p_min},
                        "scan_stage_ms": d_mean,
                        "scan_stage_frac_of_hbm_peak": decode_bytes / (d_mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -616,6 +740,7 @@ def main():
                        "kept_per_image": float(counts[0].mean()), "mode": "agnostic, thr 0.05, IoU 0.5",
                        "per_class_images_per_s": BATCH / (per_class_ms * 1e-3),
                        "pipeline_class_ms_per_batch": pipe_ms,
+                       "pipeline_class_trials_ms_per_batch": pipe_trials,
                        "pipeline_class_images_per_s": BATCH / (pipe_ms * 1e-3)},
     }
     line["cpu_baseline"] = None

@@ -113,6 +113,15 @@ def workspace(dev, nbytes, tag="default", stream=None):
     return buf
 
 
+def keep_for_graphs(*tensors):
+    """Buffers whose addresses a stream capture has baked into a graph: held until the process
+    ends, since any later replay reads and writes them."""
+    with _cache_lock:
+        for t in tensors:
+            if t is not None and not any(t is k for k in _captured):
+                _captured.append(t)
+
+
 # --------------------------------------------------------------------------- anchors
 def make_anchor_cfg(pyramid_levels=None, strides=None, sizes=None, ratios=None, scales=None):
     cfg = _lib.AnchorCfg()

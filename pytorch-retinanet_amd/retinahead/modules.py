@@ -149,7 +149,10 @@ class _AssignAhead:
 
     def next_for(self, cls, anchors, using):
         """What the step now starting carries for the next one: (annotations, workspace, small
-        outputs), or None.  ``using``: the workspace this step itself reads, if it is one of ours."""
+        outputs), or None.  ``using``: the workspace this step itself reads, if it is one of ours.
+        Under stream capture the workspace and the small outputs handed out here are pinned: a
+        replay of the graph writes to their addresses, so they are neither dropped from the
+        rotation nor freed while the process lives."""
         st = self.by_device.get(cls.device.index)
         asked = st and st["asked"]
         if not asked:
@@ -161,14 +164,27 @@ class _AssignAhead:
             return None                 # another batch size, class count or anchor set: not ours
         lib = _lib.load()
         need = F._focal_ws_bytes(lib, cls.shape[0], cls.shape[1], cls.shape[2], ann.shape[1])
+        pinned = st.setdefault("pinned", [])
         ws = next((b for b in st["bufs"] if b is not using and b.numel() >= need), None)
         if ws is None:
             ws = F.focal_workspace(cls.shape[0], cls.shape[1], cls.shape[2], ann.shape[1], cls.device)
             st["bufs"].append(ws)
-            del st["bufs"][:-3]
+            # three eager workspaces take turns; the ones a captured graph addresses stay
+            old, st["bufs"] = st["bufs"][:-3], st["bufs"][-3:]
+            st["bufs"][:0] = [b for b in old if any(b is q for q in pinned)]
         out = F.new_small_outputs(cls.shape[0], cls.device)
+        if torch.cuda.is_current_stream_capturing():
+            self.pin(st, ws, out)
         st["ready"] = {"key": key, "ann": ann, "ws": ws, "out": out}
         return ann, ws, out
+
+    @staticmethod
+    def pin(st, ws, out):
+        """Keeps a workspace and a step's small outputs alive for the graphs that captured them."""
+        pinned = st.setdefault("pinned", [])
+        if not any(ws is q for q in pinned):
+            pinned.append(ws)
+        F.keep_for_graphs(ws, dict.__getitem__(out, "small"))
 
 
 def _is_unit(g):
@@ -236,6 +252,9 @@ def _run_fused(fn, tensors, cfg):
         hit = ahead.take(anchors, annotations, cls.shape[-1], cfg)
         nxt = ahead.next_for(cls, anchors, hit["ws"] if hit else None)
         if hit is not None:     # this step's assignment came with the previous step
+            if torch.cuda.is_current_stream_capturing():
+                # made by an eager (warm-up) step, read and written by every replay from now on
+                ahead.pin(ahead.by_device[cls.device.index], hit["ws"], hit["out"])
             return fn(*tensors, stages=_lib.STAGE_STREAM | _lib.STAGE_FINALIZE, out=hit["out"],
                       ws=hit["ws"], ahead=nxt, **kw)
         return fn(*tensors, ahead=nxt, **kw)

@@ -144,6 +144,72 @@ def test_prefetch_in_two_alternating_graphs(rh):
             assert torch.equal(got[k], want[k]), (i, k)
 
 
+def test_captured_prefetch_buffers_outlive_eager_steps_of_other_shapes(rh):
+    """Two graphs are captured as above; then more than three eager steps with growing annotation
+    lists make the module allocate new workspaces and rotate its old ones out, the loss tensors
+    the captures returned are dropped, and the allocator is asked to give freed blocks back.  The
+    graphs' workspaces and small outputs must have stayed alive: replaying them still gives the
+    plain results."""
+    import gc
+    size, c = 128, 20
+    batches = [make_batch(90 + i, 2, size, c, 5, [5, 2]) for i in range(5)]
+    anc = dev(batches[0][2])
+    s_cls = dev(batches[0][0]).requires_grad_(True)
+    s_reg = dev(batches[0][1]).requires_grad_(True)
+    s_ann = [dev(batches[0][3]), dev(batches[1][3])]
+    mod = rh.FocalLoss()
+
+    def step(i):
+        s_cls.grad = None
+        s_reg.grad = None
+        mod.prefetch_assignment(anc, s_ann[(i + 1) % 2], c)
+        out = mod(s_cls, s_reg, anc, s_ann[i % 2])
+        sum(out.values()).backward()
+        return s_cls.grad, s_reg.grad       # the loss tensors are dropped at once
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):
+            step(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graphs, grads = [], []
+    for i in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            grads.append(step(i))
+        graphs.append(g)
+    st = mod.cfg["ahead"].by_device[anc.device.index]
+    assert len(st["pinned"]) == 2
+    pinned_ptrs = sorted(b.data_ptr() for b in st["pinned"])
+    # eager steps of other shapes: every one needs a larger workspace than any the module holds
+    for k, m in enumerate((40, 90, 150, 220)):
+        cls, reg, _, ann = make_batch(95 + k, 2, size, c, m, [m, 1])
+        nxt = dev(make_batch(99 + k, 2, size, c, m + 20, [3, 3])[3])
+        mod.prefetch_assignment(anc, nxt, c)
+        run_step(mod, dev(cls), dev(reg), anc, dev(ann))
+    assert sorted(b.data_ptr() for b in st["pinned"]) == pinned_ptrs
+    assert all(any(b is q for q in st["bufs"]) for b in st["pinned"])
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]   # reuse freed blocks
+    plain = rh.FocalLoss()
+    mod.cfg["ahead"].by_device[anc.device.index]["ready"] = None
+    # batch 0's assignment has to be in the workspace graph 0 reads: graph 1 writes it
+    s_ann[0].copy_(dev(batches[0][3]))
+    graphs[1].replay()
+    for i in range(len(batches) - 1):
+        s_cls.data.copy_(dev(batches[i][0]))
+        s_reg.data.copy_(dev(batches[i][1]))
+        s_ann[(i + 1) % 2].copy_(dev(batches[i + 1][3]))
+        graphs[i % 2].replay()
+        torch.cuda.synchronize()
+        want = run_step(plain, dev(batches[i][0]), dev(batches[i][1]), anc, dev(batches[i][3]))
+        assert torch.equal(grads[i % 2][0], want[2]) and torch.equal(grads[i % 2][1], want[3]), i
+    del junk
+
+
 def test_assignment_stage_on_its_own_stream(rh):
     """functional.focal_assign: the assignment stage issued apart (here on a second stream, ordered
     by events) into a workspace of its own; the remaining stages then give the plain call's bits."""

@@ -276,3 +276,67 @@ def test_data_parallel_global_normaliser():
     assert np.allclose(np.concatenate([t[5] for t in res]), want["d_classifications"], rtol=1e-5,
                        atol=1e-12)
     assert np.allclose(np.concatenate([t[6] for t in res]), want["d_regressions"], rtol=1e-5, atol=1e-9)
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's own multi-rank skeleton (exchange, fences, rank count, per-block max over ranks)
+    under gloo, with a stand-in for the GPU step: each rank's 'launch' leaves (rank + 1) * its step
+    count in the four-float exchange vector."""
+    import time
+    import torch.distributed as dist
+    for p in (ROOT, PKG_DIR):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = bench.RankExchange(world, "gloo")
+    calls = [0]
+    syncs = [0]
+
+    def step():
+        calls[0] += 1
+        if rank == 1:
+            time.sleep(0.002)                      # the slow rank sets every block's time
+        ex.submit(torch.full((4,), float((rank + 1) * calls[0])))
+
+    def sync():
+        syncs[0] += 1
+    seen = bench.count_ranks(world, "gloo", torch.device("cpu"))
+    blocks = bench.timed_blocks(step, ex, sync, steps=5, warmup=2, repeats=3, world=world,
+                                backend="gloo", dev=torch.device("cpu"))
+    q.put((rank, seen, calls[0], syncs[0], blocks.tolist(), ex.last.tolist(), len(ex.pending)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_skeleton_under_gloo():
+    """What `bench.py --gpus N` does around its step, run by two CPU ranks: both ranks are counted,
+    every step's vector is summed over the ranks, each timed block is bracketed by fences (two
+    synchronisations each) and reported as the slowest rank's time, nothing is left pending."""
+    import bench
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, calls, syncs, blocks, last, pending in res:
+        assert seen == world and calls == 2 + 3 * 5 and pending == 0
+        assert syncs == 2 * (1 + 3)                       # the warm-up fence and one per block
+        assert last == [float(3 * calls)] * 4             # (1 + 2) * the step count, on every rank
+        assert len(blocks) == 3 and min(blocks) >= 5 * 0.002
+    assert res[0][4] == res[1][4]                         # per block, the slowest rank, on all ranks
+    # a scaling run that is not what it says is refused
+    bench.require_ranks(2, 2, 8, "nccl")
+    with pytest.raises(SystemExit):
+        bench.require_ranks(1, 2, 8, "nccl")
+    with pytest.raises(SystemExit):
+        bench.require_ranks(2, 2, 1, "nccl")
+    bench.require_ranks(2, 2, 1, "gloo")                  # the one-card rehearsal is asked for by name
