@@ -584,7 +584,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // device-scope atomic stores; they are read as device-scope atomic loads, again and again until
 // each carries the call's tag.
 // ---------------------------------------------------------------------------
-constexpr int kFinalBatch = 9;
+constexpr int kFinalBatch = 8;
 constexpr int kFinishSpins = 1 << 21;   // about two seconds of polling before giving up
 struct ImageLoss {
   float cl, rl;
@@ -615,14 +615,25 @@ __device__ __forceinline__ void store_atom_coherent(unsigned long long* p, const
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// All 64 lanes of one wave; every lane returns the image's results.  kBatch: records requested
-// together per lane (18 for the polling reader, one round for an image of 1084 tiles, would not
-// fit the stream kernel's 96 registers: 256 bytes of spill and a slower kernel for everyone).
-template <bool kCoherent, int kBatch>
-__device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int j) {
+// The image's sums are defined over kFinalShares interleaved shares of its records: share s holds
+// the records base + 64 s + lane + 256 i (i = 0, 1, ..), each lane adds its records in ascending
+// order in double, a butterfly adds the 64 lanes, and the shares are added as (S0 + S1) + (S2 + S3).
+// One wave can work through all shares (kWaves = 1: consecutive loads of a lane belong to
+// consecutive shares) or four waves one share each (kWaves = 4, wave w share w, combined through
+// s_fin): the same additions in the same order, so the same bits.
+// kBatch (a multiple of kFinalShares): records requested together per lane; 16 for the polling
+// reader would not fit the stream kernel's 96 registers (spills, and a slower kernel for everyone).
+constexpr int kFinalShares = 4;
+template <bool kCoherent, int kBatch, int kWaves>
+__device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int j, double* s_fin) {
+  static_assert(kBatch % kFinalShares == 0 && (kWaves == 1 || kWaves == kFinalShares), "shares");
   const int lane = threadIdx.x & 63;
+  const int wave = kWaves == 1 ? 0 : (int)(threadIdx.x >> 6);
   const int nblk = f.nblk, N = f.N, tile_mode = f.tile_mode;
-  double c = 0.0, r = 0.0;
+  constexpr int kAcc = kWaves == 1 ? kFinalShares : 1;
+  double c[kAcc], r[kAcc];
+#pragma unroll
+  for (int a = 0; a < kAcc; ++a) c[a] = r[a] = 0.0;
   bool timed_out = false;
   // the small loads go out with the first batch of records, not after the last
   int npv[4];
@@ -639,17 +650,16 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
     const bool shared_first = (first % kTileRows) != 0;
     const int u_shared = (t_lo + 1) * tile_mode;      // records below it belong to tile t_lo
     // (kBatch loads in flight per lane, only the half of each record that belongs to
-    // this image, and the small loads above issued with them: 6.0 -> 5.4 us for the kernel at
-    // 1084 tiles per image.  Twice the batch changes nothing.)
+    // this image, and the small loads above issued with them.)
     const int u_end = (t_hi + 1) * tile_mode;
     const unsigned long long* atoms = reinterpret_cast<const unsigned long long*>(f.partials);
 #pragma nounroll
-    for (int u0 = t_lo * tile_mode + lane; u0 < u_end; u0 += 64 * kBatch) {
+    for (int u0 = t_lo * tile_mode + wave * 64 + lane; u0 < u_end; u0 += 64 * kWaves * kBatch) {
       unsigned long long qc[kBatch], qr[kBatch];   // this image's two atoms of each record
       for (int spin = 0;; ++spin) {
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
-          const int u = min(u0 + k * 64, u_end - 1);
+          const int u = min(u0 + k * 64 * kWaves, u_end - 1);
           const size_t at = 4 * (size_t)u + 2 * (shared_first && u < u_shared);
           if (kCoherent) {
             qc[k] = load_atom_coherent(atoms + at);
@@ -663,8 +673,9 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
         // written during this launch: wait until every atom carries the call's tag
         bool all_in = true;
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-          all_in &= (unsigned)(qc[k] >> 32) == f.tag && (unsigned)(qr[k] >> 32) == f.tag;
+        for (int k = 0; k < kBatch; ++k)      // (a load past the end repeats the image's last record,
+          all_in &= u0 + k * 64 * kWaves >= u_end ||      // which its owner may have consumed by now)
+                    ((unsigned)(qc[k] >> 32) == f.tag && (unsigned)(qr[k] >> 32) == f.tag);
         if (__ballot(!all_in) == 0ull) break;
         if (spin >= kFinishSpins) {          // (a logic error: report it, do not hang)
           timed_out = true;
@@ -674,11 +685,11 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
       }
 #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
-        if (u0 + k * 64 < u_end) {
-          c += __uint_as_float((unsigned)qc[k]);
-          r += __uint_as_float((unsigned)qr[k]);
+        if (u0 + k * 64 * kWaves < u_end) {
+          c[kWaves == 1 ? k % kFinalShares : 0] += __uint_as_float((unsigned)qc[k]);
+          r[kWaves == 1 ? k % kFinalShares : 0] += __uint_as_float((unsigned)qr[k]);
           if (kCoherent) {      // consumed: tag 0 again, which no call expects
-            const int u = u0 + k * 64;
+            const int u = u0 + k * 64 * kWaves;
             const size_t at = 4 * (size_t)u + 2 * (shared_first && u < u_shared);
             unsigned long long* w = const_cast<unsigned long long*>(atoms);
             store_atom_coherent(w + at, qc[k] & 0xFFFFFFFFull);
@@ -688,13 +699,19 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
       }
     }
   } else {
-    // (unrolled: the loads of eight rounds go out together instead of one latency each)
     const float2* pj = reinterpret_cast<const float2*>(f.partials) + (size_t)j * f.generic_blocks;
-#pragma unroll 8
-    for (int t = lane; t < f.generic_blocks; t += 64) {
-      const float2 q = pj[t];
-      c += q.x;
-      r += q.y;
+#pragma nounroll
+    for (int t0 = wave * 64 + lane; t0 < f.generic_blocks; t0 += 64 * kWaves * kBatch) {
+      float2 q[kBatch];        // (the loads of a round go out together instead of one latency each)
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) q[k] = pj[min(t0 + k * 64 * kWaves, f.generic_blocks - 1)];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        if (t0 + k * 64 * kWaves < f.generic_blocks) {
+          c[kWaves == 1 ? k % kFinalShares : 0] += q[k].x;
+          r[kWaves == 1 ? k % kFinalShares : 0] += q[k].y;
+        }
+      }
     }
   }
   int np = 0;
@@ -702,18 +719,42 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
   for (int k = 0; k < 4; ++k) np += lane + k * 64 < nblk ? npv[k] : 0;
   for (int i = lane + 256; i < nblk; i += 64) np += f.blk_pos[(size_t)j * nblk + i];
   const bool empty = gtc == 0;
-  c = wave_sum(c);
-  r = wave_sum(r);
   np = wave_sum(np);
+  double ct, rt;
+  if (kWaves == 1) {
+#pragma unroll
+    for (int a = 0; a < kAcc; ++a) {
+      c[a] = wave_sum(c[a]);
+      r[a] = wave_sum(r[a]);
+    }
+    ct = (c[0] + c[kAcc > 1 ? 1 : 0]) + (c[kAcc > 2 ? 2 : 0] + c[kAcc > 3 ? 3 : 0]);
+    rt = (r[0] + r[kAcc > 1 ? 1 : 0]) + (r[kAcc > 2 ? 2 : 0] + r[kAcc > 3 ? 3 : 0]);
+  } else {
+    // one share per wave: combined through LDS (s_fin: 2 * kFinalShares + 1 doubles)
+    const double cw = wave_sum(c[0]), rw = wave_sum(r[0]);
+    const bool any_out = __ballot(timed_out) != 0ull;
+    __syncthreads();
+    if (lane == 0) {
+      s_fin[wave] = cw;
+      s_fin[kFinalShares + wave] = rw;
+    }
+    if (threadIdx.x == 0) s_fin[2 * kFinalShares] = 0.0;
+    __syncthreads();
+    if (any_out && lane == 0) s_fin[2 * kFinalShares] = 1.0;
+    __syncthreads();
+    ct = (s_fin[0] + s_fin[1]) + (s_fin[2] + s_fin[3]);
+    rt = (s_fin[kFinalShares] + s_fin[kFinalShares + 1]) + (s_fin[kFinalShares + 2] + s_fin[kFinalShares + 3]);
+    timed_out = s_fin[2 * kFinalShares] != 0.0;
+  }
   // batch-wide normaliser: every image is divided by the one total (an image's share of
   // the batch loss); otherwise by its own count, losses.py:94 and :134
   const float npf = f.pos_total ? total : (float)np;
   ImageLoss out;
-  out.cl = empty ? 0.f : (float)c / fmaxf(npf, 1.f);
-  out.rl = (empty || np == 0) ? 0.f : (float)r / (4.0f * npf);
+  out.cl = empty ? 0.f : (float)ct / fmaxf(npf, 1.f);
+  out.rl = (empty || np == 0) ? 0.f : (float)rt / (4.0f * npf);
   out.pos = np;
   if (timed_out) out.cl = out.rl = __builtin_nanf("");
-  if (lane == 0) {
+  if (lane == 0 && wave == 0) {
     if (f.per_image) {
       f.per_image[j] = out.cl;
       f.per_image[f.B + j] = out.rl;
@@ -748,7 +789,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(const FinalIn f
   for (int j0 = 0; j0 < f.B; j0 += kFinalThreads / 64) {
     const int j = j0 + wave;
     ImageLoss il{0.f, 0.f, 0};
-    if (j < f.B) il = finalize_image<false, kFinalBatch>(f, j);
+    if (j < f.B) il = finalize_image<false, kFinalBatch, 1>(f, j, nullptr);
     __syncthreads();
     if (lane == 0) {
       s_img[0][wave] = il.cl;
@@ -790,15 +831,18 @@ struct StreamFinal {
   FinalIn in;
 };
 
-// One wave: reduces image j as its records arrive and publishes the image's results the same
-// way, as three tagged atoms; the finisher of image 0 then collects all images (polling, like
-// the records) and forms the batch means.
+// The finishing workgroup of image j (all its waves, a share of the records each): reduces the
+// image as its records arrive and publishes the image's results the same way, as three tagged
+// atoms; wave 0 of the finisher of image 0 then collects all images (polling, like the records)
+// and forms the batch means.
 __device__ __forceinline__ void stream_finish_image(const StreamFinal& fin, const int j) {
+  __shared__ double s_fin[2 * kFinalShares + 1];
   const int lane = threadIdx.x & 63;
   FinalIn in = fin.in;
   const unsigned tag = *fin.epoch;
   in.tag = tag;
-  const ImageLoss il = finalize_image<true, kFinalBatch>(in, j);
+  const ImageLoss il = finalize_image<true, kFinalBatch, kFinalShares>(in, j, s_fin);
+  if (threadIdx.x >= 64) return;
   unsigned long long* out = reinterpret_cast<unsigned long long*>(fin.img_out);
   if (lane == 0) {
     store_atom_coherent(out + 3 * (size_t)j, make_atom(il.cl, tag));
@@ -864,7 +908,7 @@ __device__ __forceinline__ void stream_finish_image(const StreamFinal& fin, cons
 // Five waves per SIMD (at most 96 vector registers; the compiler's own choice was 99, i.e. four
 // waves): measured 120.0 against 121.5 us.  Six waves need spills and take 156 us.
 //
-// kAhead: the launch also carries the IoU assignment of the NEXT step (its annotations are known
+// kAhead != 0: the launch also carries the IoU assignment of the NEXT step (its annotations are known
 // before its predictions are).  Its workgroups are the last of the grid, image-major from the
 // long blocks down like the stand-alone kernel's: they take the workgroup slots that the stream
 // leaves empty as its last tiles drain, and end about 6 us after it, against 11 us plus a kernel
@@ -880,7 +924,8 @@ struct AheadArgs {
   int nblk;
 };
 
-template <int U, bool kLogits, bool kAhead>
+// kAhead: 0 no assignment rides along, 1 the plain form, 2 the split form (long annotation lists)
+template <int U, bool kLogits, int kAhead>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) void focal_stream_kernel(
     const float* __restrict__ prob, float* __restrict__ dprob, const float* __restrict__ reg,
     float* __restrict__ dreg, const float4* __restrict__ anchors, const GtRec* __restrict__ gt,
@@ -896,13 +941,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5))) v
     const int extra = (int)blockIdx.x - units;
     const int finishers = fin.enabled ? fin.in.B : 0;
     if (extra < finishers) {
-      if (threadIdx.x < 64) stream_finish_image(fin, extra);
+      stream_finish_image(fin, extra);
       return;
     }
     if (kAhead) {
       const int at = extra - finishers;
       const int b = at / ahead.batch;
-      assign_block<false>(ahead.aa, at - b * ahead.batch, ahead.nblk - 1 - b, ahead.nblk);
+      assign_block<kAhead == 2>(ahead.aa, at - b * ahead.batch, ahead.nblk - 1 - b, ahead.nblk);
     }
     return;
   }
@@ -1791,7 +1836,7 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
       }
       AheadArgs ahead{};
       int ahead_blocks = 0;
-      const bool ride = next && !assign_split(next->m) &&
+      const bool ride = next &&
                         (long long)num_tiles * parts + (long long)batch * wn.nblk < (1ll << 31);
       if (ride) {
         ahead.aa = assign_args(anchors, next->annotations, n, next->m, num_classes,
@@ -1802,11 +1847,14 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
         ahead_blocks = batch * wn.nblk;
         next_assigned = true;
       }
-      auto kern = params->from_logits
-                      ? (u5 ? (ride ? focal_stream_kernel<5, true, true> : focal_stream_kernel<5, true, false>)
-                            : (ride ? focal_stream_kernel<4, true, true> : focal_stream_kernel<4, true, false>))
-                      : (u5 ? (ride ? focal_stream_kernel<5, false, true> : focal_stream_kernel<5, false, false>)
-                            : (ride ? focal_stream_kernel<4, false, true> : focal_stream_kernel<4, false, false>));
+      const int form = !ride ? 0 : (assign_split(next->m) ? 2 : 1);
+      typedef decltype(&focal_stream_kernel<5, false, 0>) StreamKernel;
+      static const StreamKernel table[2][2][3] = {
+          {{focal_stream_kernel<4, false, 0>, focal_stream_kernel<4, false, 1>, focal_stream_kernel<4, false, 2>},
+           {focal_stream_kernel<4, true, 0>, focal_stream_kernel<4, true, 1>, focal_stream_kernel<4, true, 2>}},
+          {{focal_stream_kernel<5, false, 0>, focal_stream_kernel<5, false, 1>, focal_stream_kernel<5, false, 2>},
+           {focal_stream_kernel<5, true, 0>, focal_stream_kernel<5, true, 1>, focal_stream_kernel<5, true, 2>}}};
+      const StreamKernel kern = table[u5 ? 1 : 0][params->from_logits ? 1 : 0][form];
       hipLaunchKernelGGL(kern, dim3(num_tiles * parts + (fin.enabled ? batch : 0) + ahead_blocks),
                          dim3(kThreads), 0, s,
                          classifications, d_classifications, regressions, d_regressions,

@@ -76,6 +76,27 @@ def main():
             extra = f"  algo {algo / mean / 1e6:8.1f} GB/s (mean) {algo / mn / 1e6:8.1f} (min)" \
                 if name in ("stream", "all") else ""
             print(f"{name:9s} mean {mean * 1e3:8.1f} us  min {mn * 1e3:8.1f} us{extra}")
+        if not a.logits:
+            # the step as a loop that announces the next batch runs it: one launch (stream, the
+            # reduction inside it, the next step's assignment at the end of its grid), two
+            # workspaces in turn; trains of 20 back-to-back steps
+            wss = [F.focal_workspace(bsz, n, c, m, dev) for _ in range(2)]
+            outs = [F.focal_loss_fwd_bwd(cls, reg, anchors, ann, ws=wss[i]) for i in range(2)]
+            turn = [0]
+
+            def step():
+                i = turn[0] & 1
+                turn[0] += 1
+                F.focal_loss_fwd_bwd(cls, reg, anchors, ann, stages=_lib.STAGE_STREAM | _lib.STAGE_FINALIZE,
+                                     out=outs[i], ws=wss[i], ahead=(ann, wss[1 - i], outs[1 - i]))
+            for _ in range(10):
+                step()
+            mean, mn = bench.event_train(step, 20, 10)
+            print(f"step, look-ahead, one launch: mean {mean * 1e3:8.1f} us  best train {mn * 1e3:8.1f} us"
+                  f"  algo {algo / mean / 1e6:8.1f} GB/s = {algo / mean / 1e6 / 8000:.3f} of the HBM peak")
+            ref = F.focal_loss_fwd_bwd(cls, reg, anchors, ann)
+            assert torch.equal(ref["losses"], outs[0]["losses"]) and torch.equal(ref["losses"], outs[1]["losses"])
+            assert torch.equal(ref["d_classifications"], outs[0]["d_classifications"])
     else:
         icls_np, ireg_np = bench.synth_infer(rng, bsz, n, c)
         icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
