@@ -208,6 +208,31 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
   }
   const float ux1 = wave_extreme<false>(lo_x), uy1 = wave_extreme<false>(lo_y);
   const float ux2 = wave_extreme<true>(hi_x), uy2 = wave_extreme<true>(hi_y);
+  // When only the packed codes are wanted (the loss), a pair matters only if its IoU can reach
+  // the lower of the two thresholds t: below it the anchor's state does not depend on the pair
+  // (an anchor whose other IoUs all stay below t is a negative either way), and a maximum at or
+  // above t is never one of the pairs left out, so state, arg-max and label are unchanged.  The
+  // IoU is at most the ratio of the smaller area to the larger (the float32 quotient stays
+  // within 1e-6 of that: both areas and the intersection are products of rounded differences,
+  // and rounding is monotone), so a box whose area is below t times the smallest anchor area of
+  // the wave, or above the largest divided by t, is dropped with the same ballot as the boxes
+  // that miss the wave's bounding box.  The maximum IoU itself (rh_assign's output) needs them all.
+  float a_lo = 0.0f, a_hi = __builtin_inff();     // a box is kept when a_lo <= its area <= a_hi
+  float t_side = -1.0f;                           // ... and t_side of each of its sides reaches into the wave's box
+  if (!state && !argmax && !label && !iou_max) {
+    float amin = area_a[0], amax = area_a[0];
+#pragma unroll
+    for (int k = 1; k < kAssignPer; ++k) {
+      amin = vmin(amin, area_a[k]);
+      amax = vmax(amax, area_a[k]);
+    }
+    const float t = fminf(neg_thresh, pos_thresh) * 0.9999f;
+    if (t > 0.0f) {
+      a_lo = wave_extreme<false>(amin) * t;
+      a_hi = wave_extreme<true>(amax) / t;
+      t_side = t * 0.999f;
+    }
+  }
 
   RH_MARK(1);
   int cnt = 0;        // valid GT rows seen so far
@@ -246,7 +271,13 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
       continue;
     }
     // rows whose box reaches into the wave's bounding box; a NaN coordinate is never culled
-    const bool apart = (r.x2 <= ux1) | (r.x1 >= ux2) | (r.y2 <= uy1) | (r.y1 >= uy2);
+    // (codes only, as above: IoU >= t needs the intersection to cover t of the box's own area,
+    // hence t of its width and of its height; an anchor's overlap with the box is within the
+    // overlap of the wave's bounding box with it)
+    const float ovx = vmin(r.x2, ux2) - vmax(r.x1, ux1), ovy = vmin(r.y2, uy2) - vmax(r.y1, uy1);
+    const bool apart = (r.x2 <= ux1) | (r.x1 >= ux2) | (r.y2 <= uy1) | (r.y1 >= uy2) |
+                       (rarea < a_lo) | (rarea > a_hi) | (ovx < (r.x2 - r.x1) * t_side) |
+                       (ovy < (r.y2 - r.y1) * t_side);
     unsigned long long hm = __ballot(valid & !apart);
     while (hm) {
       const int src = __builtin_ctzll(hm);
