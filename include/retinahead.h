@@ -7,7 +7,8 @@
  *   - Pointers named in the comments as "device" are raw HIP device pointers;
  *     the library never allocates, frees or copies to the host.  Temporary
  *     storage is a caller-owned workspace whose size the matching
- *     *_workspace_bytes() query returns (align it to 256 bytes).
+ *     *_workspace_bytes() query returns (align it to 256 bytes; its contents
+ *     need no initialisation, no entry point reads what it has not written).
  *   - `stream` is a hipStream_t (NULL = the default stream).  Work is enqueued
  *     on it for the CALLER'S CURRENT DEVICE; nothing synchronises.
  *   - Return value: RH_OK or a negative RH_E* code; rh_last_error() gives the
@@ -177,11 +178,11 @@ void rh_focal_params_default(rh_focal_params* p);
  * workspace's next assignment after the stages that still read it).
  * RH_STAGE_STREAM | RH_STAGE_FINALIZE in one call reduce inside the stream launch (no further
  * kernel); run apart they give the same bits.  Either way the workspace must have had its
- * RH_STAGE_ASSIGN since it was allocated or last used for another shape.
- * Zero-fill a workspace once before its first use (hipMemsetAsync): the reduction inside the
- * launch tells the records of the current call from older bytes by a 32-bit tag that is never
- * zero and changes with every call; bytes left behind by another user of the memory could carry
- * the current tag by chance (2^-31 per record). */
+ * RH_STAGE_ASSIGN for these annotations since it was allocated or last used for anything else:
+ * that is the only requirement on its contents.  The workspace needs no initialisation: the
+ * reduction inside the launch tells the records of the current call from older bytes by a 32-bit
+ * tag that is never zero and changes with every call, and the assignment stage clears the tags of
+ * every record the call will poll, so nothing the memory held before can pass for one. */
 enum rh_focal_stage {
   RH_STAGE_ASSIGN = 1,   /* GT compaction + IoU assignment + num_pos            */
   RH_STAGE_STREAM = 2,   /* N x C focal stream + smooth-L1, losses and gradients */
@@ -405,7 +406,7 @@ int rh_postprocess_levels(const float* const* cls_levels, const float* const* re
 enum rh_post_stage {
   RH_POST_DECODE = 1, /* class max + threshold + decode + clip + compaction */
   RH_POST_SORT = 2,   /* per-image sort by (score desc, anchor index asc)   */
-  RH_POST_NMS = 4,    /* IoU bitmask + greedy sweep + output gather         */
+  RH_POST_NMS = 4,    /* overlapping pairs + greedy resolve + output gather */
   RH_POST_ALL = 7
 };
 

@@ -142,7 +142,15 @@ struct AssignArgs {
   int* label;
   float* iou_max;
   int* blk_pos;
+  int batch;
   unsigned* epoch;   // of the loss call that follows (null: none): advanced here
+  // record atoms of the loss call that follows (the tile partials, then the per-image results):
+  // the assignment stage clears them, so that no byte the workspace held before -- another
+  // caller's data, records of another shape -- can be taken for a record of that call
+  unsigned long long* clear_a;
+  long long clear_a_count;
+  unsigned long long* clear_b;
+  int clear_b_count;
   int N, M, C;
   float neg_thresh, pos_thresh;
   CodeLayout lay;
@@ -176,6 +184,13 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
   RH_MARK(0);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (aa.clear_a) {       // this block's share of the record atoms, interleaved by thread
+    const long long step = (long long)aa.batch * nblk * kThreads;
+    for (long long i = ((long long)j * nblk + bx) * kThreads + threadIdx.x; i < aa.clear_a_count; i += step)
+      aa.clear_a[i] = 0ull;
+    if (bx == 0 && j == 0)
+      for (int i = threadIdx.x; i < aa.clear_b_count; i += kThreads) aa.clear_b[i] = 0ull;
+  }
   // anchors of thread t: base + k * stride.  Split form: every wave holds the same anchors.
   constexpr int kStride = kSplit ? 64 : kThreads;
   const int base = kSplit ? bx * kSplitAnchors + lane : bx * kAssignBlock + (int)threadIdx.x;
@@ -1509,6 +1524,7 @@ struct LossWorkspace {
   int nblk;
   int* code;
   float* partials;
+  long long partial_count;   // floats
   float* pos_total;  // [1] positives of the whole call (batch-wide normaliser only)
   unsigned* epoch;   // [1] tag of the records of the call in flight (in-launch final reduction)
   float* img_out;    // [B][6] per-image results on their way to the batch means (three atoms)
@@ -1541,7 +1557,8 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   w.nblk = assign_blocks(n, m);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
-  w.partials = cv.take<float>((size_t)partial_floats(batch, n, c));
+  w.partial_count = partial_floats(batch, n, c);
+  w.partials = cv.take<float>((size_t)w.partial_count);
   w.pos_total = cv.take<float>(1);
   w.epoch = cv.take<unsigned>(1);
   w.img_out = cv.take<float>((size_t)batch * 6);
@@ -1560,7 +1577,7 @@ static int check_assign_shapes(int batch, long long n, int m, int c) {
   return RH_OK;
 }
 
-static AssignArgs assign_args(const float* anchors, const float* annotations, long long n, int m,
+static AssignArgs assign_args(const float* anchors, const float* annotations, int batch, long long n, int m,
                               int c, float neg_t, float pos_t, const LossWorkspace& w, int* code,
                               unsigned char* state, int* argmax, int* label, float* iou_max,
                               int* status, const CodeLayout& lay) {
@@ -1576,7 +1593,12 @@ static AssignArgs assign_args(const float* anchors, const float* annotations, lo
   aa.label = label;
   aa.iou_max = iou_max;
   aa.blk_pos = w.blk_pos;
+  aa.batch = batch;
   aa.epoch = w.epoch;
+  aa.clear_a = w.epoch ? reinterpret_cast<unsigned long long*>(w.partials) : nullptr;
+  aa.clear_a_count = w.partial_count / 2;
+  aa.clear_b = reinterpret_cast<unsigned long long*>(w.img_out);
+  aa.clear_b_count = w.img_out ? batch * 3 : 0;
   aa.N = (int)n;
   aa.M = m;
   aa.C = c;
@@ -1593,7 +1615,7 @@ static int launch_assign(const float* anchors, const float* annotations, int bat
   RH_REQUIRE(w.nblk <= 65535, RH_ESHAPE, "n=%lld with m=%d: more than 65535 assignment blocks per image", n, m);
   dim3 grid((unsigned)batch, (unsigned)w.nblk);
   hipLaunchKernelGGL(assign_split(m) ? assign_kernel<true> : assign_kernel<false>, grid, dim3(kThreads), 0, s,
-                     assign_args(anchors, annotations, n, m, c, neg_t, pos_t, w, code, state, argmax,
+                     assign_args(anchors, annotations, batch, n, m, c, neg_t, pos_t, w, code, state, argmax,
                                  label, iou_max, status, lay));
   RH_CHECK_LAUNCH("assign_kernel");
   return RH_OK;
@@ -1870,7 +1892,7 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
       const bool ride = next &&
                         (long long)num_tiles * parts + (long long)batch * wn.nblk < (1ll << 31);
       if (ride) {
-        ahead.aa = assign_args(anchors, next->annotations, n, next->m, num_classes,
+        ahead.aa = assign_args(anchors, next->annotations, batch, n, next->m, num_classes,
                                params->neg_thresh, params->pos_thresh, wn, wn.code, nullptr, nullptr,
                                nullptr, nullptr, next->status, CodeLayout{});
         ahead.batch = batch;

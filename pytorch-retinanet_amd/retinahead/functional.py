@@ -100,9 +100,11 @@ def workspace(dev, nbytes, tag="default", stream=None):
         if buf is None or buf.numel() < nbytes:
             # grow in steps of a quarter so that slowly growing shapes do not reallocate every call
             want = max(int(nbytes), 256) if buf is None else max(int(nbytes), buf.numel() * 5 // 4)
-            # zero-filled: the in-launch reduction tells this call's records from older bytes by a
-            # 32-bit tag that is never zero
-            buf = torch.zeros(want, dtype=torch.uint8, device=dev)
+            # not filled: no stage reads a byte that an earlier stage of the same call has not
+            # written (the loss's assignment stage clears the tags of the records that the
+            # reduction inside the stream launch polls), and an allocation that fills would
+            # become a memset node of its own when made under stream capture
+            buf = torch.empty(want, dtype=torch.uint8, device=dev)
             cache[key] = buf
             if capturing:
                 _captured.append(buf)
@@ -327,7 +329,7 @@ def focal_workspace(bsz, n, num_classes, m, dev):
     need = _focal_ws_bytes(_lib.load(), bsz, n, int(num_classes), m)
     if need == 0:
         raise RetinaHeadError(f"unsupported shape B={bsz} N={n} C={num_classes} M={m}")
-    return torch.zeros((need,), dtype=torch.uint8, device=dev)
+    return torch.empty((need,), dtype=torch.uint8, device=dev)
 
 
 def focal_assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh=0.5,
@@ -351,7 +353,7 @@ def focal_assign(anchors_t, annotations, num_classes, neg_thresh=0.4, pos_thresh
     if need == 0:
         raise RetinaHeadError(f"unsupported shape B={bsz} N={n} C={c} M={m}")
     if ws is None or ws.device != dev or ws.dtype != torch.uint8 or ws.numel() < need:
-        ws = torch.zeros((need,), dtype=torch.uint8, device=dev)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
     if out is None:
         out = new_small_outputs(bsz, dev)
     params = _focal_params(0.25, neg_thresh, pos_thresh, 1.0, 1.0, 0, False, normalizer, None, dev)

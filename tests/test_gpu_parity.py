@@ -396,18 +396,32 @@ def test_final_reduction_inside_the_stream_launch(rh, bsz, size, c, m, valid, no
     assert torch.equal(late["losses"], apart["losses"]) and torch.equal(late["per_image"], apart["per_image"])
 
 
-@pytest.mark.parametrize("fill", [0xFF, 0x01, "random"])
+@pytest.mark.parametrize("fill", [0xFF, 0x01, "random", "records"])
 def test_loss_on_a_workspace_full_of_old_bytes(rh, fill):
-    """The workspace is caller-owned memory: whatever bytes it holds before the first call (all
-    ones would read as a valid odd tag; random bytes stand for another user's data), the assignment
-    stage starts a fresh tag and the in-launch reduction gives the bits of a zero-filled one."""
+    """The workspace is caller-owned memory and needs no initialisation: whatever bytes it holds
+    before the first call (all ones would read as a valid odd tag; random bytes stand for another
+    user's data; 'records' are the tagged records a call of ANOTHER shape left behind, which land
+    on other offsets of this shape's layout), the assignment stage clears the tags the reduction
+    inside the launch polls and the call gives the bits of a zero-filled workspace."""
     F = rh.functional
     cls, reg, anc, ann = make_batch(77, 3, 192, 20, 5, [5, 0, 2])
     d = [dev(x) for x in (cls, reg, anc, ann)]
-    clean = F.focal_loss_fwd_bwd(*d, ws=F.focal_workspace(3, anc.shape[1], 20, 5, torch.device("cuda:0")))
-    ws = F.focal_workspace(3, anc.shape[1], 20, 5, torch.device("cuda:0"))
+    cuda = torch.device("cuda:0")
+    zeroed = F.focal_workspace(3, anc.shape[1], 20, 5, cuda).zero_()
+    clean = F.focal_loss_fwd_bwd(*d, ws=zeroed)
+    ws = F.focal_workspace(3, anc.shape[1], 20, 5, cuda)
     if fill == "random":
         ws.copy_(torch.randint(0, 256, ws.shape, dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).cuda())
+    elif fill == "records":
+        big = F.focal_workspace(4, anc.shape[1], 33, 9, cuda)
+        assert big.numel() >= ws.numel()
+        o_cls, o_reg, o_anc, o_ann = make_batch(78, 4, 192, 33, 9, [9, 1, 0, 4])
+        # the stream stage alone: its records stay in place (nothing consumes them)
+        bufs = F.focal_loss_fwd_bwd(dev(o_cls), dev(o_reg), dev(o_anc), dev(o_ann), ws=big)
+        for _ in range(3):
+            F.focal_loss_fwd_bwd(dev(o_cls), dev(o_reg), dev(o_anc), dev(o_ann), ws=big, out=bufs,
+                                 stages=rh._lib.STAGE_ASSIGN | rh._lib.STAGE_STREAM)
+        ws = big
     else:
         ws.fill_(fill)
     for rep in range(2):
