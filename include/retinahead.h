@@ -52,12 +52,17 @@ enum rh_status_bits {
   RH_STATUS_LABEL_RANGE = 1,  /* a valid GT row has a label outside [0, C): the
                                  reference raises IndexError at losses.py:79; here
                                  the anchor is positive with an all-zero target row */
-  RH_STATUS_NONFINITE_BOX = 2 /* a valid GT row has a NaN or infinite coordinate.  In the
+  RH_STATUS_NONFINITE_BOX = 2, /* a valid GT row has a NaN or infinite coordinate.  In the
                                  reference the NaN IoU wins torch.max (losses.py:61), so the
                                  anchor is neither below 0.4 nor at or above 0.5 and is
                                  ignored; here comparisons skip the non-finite pair and the
                                  anchor is assigned from its other boxes: results for such
-                                 an image are not the reference's */
+                                  an image are not the reference's */
+  RH_STATUS_REDUCTION_GAVE_UP = 4 /* the reduction inside the stream launch (RH_STAGE_STREAM |
+                                 RH_STAGE_FINALIZE in one call) stopped waiting for a record of
+                                 this image after about two seconds; the call's losses are NaN.
+                                 Not expected to happen: it means a workgroup of the launch never
+                                 ran or the workspace was written by someone else meanwhile */
 };
 
 int rh_version(void);

@@ -1722,10 +1722,12 @@ __global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
       // The survivors one at a time as wave-uniform values, broadcast from their lanes
       // (v_readlane), four per round.  Measured alternatives: packing them into LDS and reading
       // them back with 16-byte broadcast reads was bound by the LDS pipe, which all waves of a
-      // compute unit share (a broadcast read costs the bandwidth of 64 lanes); scalar loads of
-      // the same records, with or without glc, returned stale data now and then (records that an
-      // earlier call had left in the cache hierarchy), so they are not used for data that the
-      // kernel before has written.
+      // compute unit share (a broadcast read costs the bandwidth of 64 lanes).  (A variant with
+      // hand-written scalar loads of the same records once gave wrong keep lists; scalar loads of
+      // data that the kernel before has written are sound on this chip -- 120 000 writer / reader
+      // rounds of tools/ubench/sload_boundary.hip, with the lines resident in the scalar cache and
+      // a second stream busy, returned no old word -- so the fault was in that variant's own
+      // addressing, not in the cache; the lane broadcast is also the faster form.)
       for (u64 m = hm; m != 0ull;) {
         int src[4];
 #pragma unroll
@@ -2487,12 +2489,18 @@ std::mutex g_scratch_mutex;
 void* g_scratch_ptr[kStaticMaxDevices];   // per device: address of `scratch` there, or null
 
 // Address of the current device's copy of `scratch` (looked up on the first call per device).
-int static_scratch(void** out) {
+int static_scratch(void** out, hipStream_t stream) {
   int device = -1;
   RH_CHECK_HIP(hipGetDevice(&device));
   RH_REQUIRE(device >= 0 && device < kStaticMaxDevices, RH_EINVAL, "device %d out of range", device);
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[device]) {
+    // the look-up is a runtime call of its own, not a stream operation: it cannot be captured
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess)
+      RH_REQUIRE(cap == hipStreamCaptureStatusNone, RH_EINVAL,
+                 "rh_nms_static: the first call on a device looks the scratch address up and must be "
+                 "made outside stream capture (call it once, on any input, before capturing)");
     void* ptr = nullptr;
     RH_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     RH_REQUIRE(ptr != nullptr, RH_ELAUNCH, "hipGetSymbolAddress returned a null address");
@@ -2516,7 +2524,7 @@ int rh_nms_static(const float* boxes, const float* scores, const int32_t* labels
              "internal: %zu bytes needed for k=%lld, %u reserved", need, (long long)k,
              (unsigned)RH_NMS_STATIC_BYTES);
   void* ptr = nullptr;
-  if (int e = static_scratch(&ptr)) return e;
+  if (int e = static_scratch(&ptr, (hipStream_t)stream)) return e;
   // Nothing in the scratch has to start at zero: every stage writes what the next one reads,
   // for this call's k, before it is read.
   return rh_nms(boxes, scores, labels, k, iou_threshold, keep, keep_count, ptr,

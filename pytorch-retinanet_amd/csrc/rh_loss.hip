@@ -631,7 +631,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // each carries the call's tag.
 // ---------------------------------------------------------------------------
 constexpr int kFinalBatch = 8;
-constexpr int kFinishSpins = 1 << 21;   // about two seconds of polling before giving up
+constexpr int kFinishSpins = 1 << 21;
+constexpr int kMaxFinishers = 128;      // finishing workgroups inside a stream launch   // about two seconds of polling before giving up
 struct ImageLoss {
   float cl, rl;
   int pos;
@@ -646,6 +647,7 @@ struct FinalIn {
   int B, N, tile_mode, generic_blocks;
   const float* pos_total;
   unsigned tag;    // kCoherent readers: the tag this call's records carry
+  int* status;     // [B] per-image status words (kCoherent readers report a reduction that gave up)
 };
 
 // A tile record is four 8-byte atoms, (value, tag): classification and regression sums of the
@@ -801,6 +803,7 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
   out.pos = np;
   if (timed_out) out.cl = out.rl = __builtin_nanf("");
   if (lane == 0 && wave == 0) {
+    if (timed_out && kCoherent && f.status) atomicOr(f.status + j, (int)RH_STATUS_REDUCTION_GAVE_UP);
     if (f.per_image) {
       f.per_image[j] = out.cl;
       f.per_image[f.B + j] = out.rl;
@@ -1714,6 +1717,8 @@ static FinalIn final_in(const LossWorkspace& w, float* per_image, int* num_pos, 
   f.tile_mode = tile_mode;
   f.generic_blocks = kGenericBlocks;
   f.pos_total = nrm.total;
+  f.tag = 0u;
+  f.status = nullptr;
   return f;
 }
 
@@ -1879,7 +1884,14 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
       // record arrives and no finalize launch follows.
       StreamFinal fin{};
       fin.in = final_in(w, per_image, num_pos, batch, n, parts, nrm);
-      if (stages & RH_STAGE_FINALIZE) {
+      // (The finishers wait for records of other workgroups of the same grid.  They are the last
+      // workgroups of the grid, and HIP dispatches a grid in index order in practice but does not
+      // promise to; with no more finishers than the chip has compute units they could not keep
+      // the stream's workgroups from running even if they all started first -- larger batches
+      // reduce in a launch of their own.  The wait is bounded either way: a reduction that gives
+      // up leaves NaN losses and RH_STATUS_REDUCTION_GAVE_UP in the image's status word.)
+      if ((stages & RH_STAGE_FINALIZE) && batch <= kMaxFinishers) {
+        fin.in.status = status;
         fin.enabled = 1;
         fin.epoch = w.epoch;
         fin.img_out = w.img_out;

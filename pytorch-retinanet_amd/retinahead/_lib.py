@@ -15,6 +15,7 @@ RH_OK = 0
 RH_NEGATIVE, RH_IGNORE, RH_POSITIVE = 0, 1, 2
 RH_STATUS_LABEL_RANGE = 1
 RH_STATUS_NONFINITE_BOX = 2
+RH_STATUS_REDUCTION_GAVE_UP = 4
 STAGE_ASSIGN, STAGE_STREAM, STAGE_FINALIZE, STAGE_ALL = 1, 2, 4, 7
 POST_DECODE, POST_SORT, POST_NMS, POST_ALL = 1, 2, 4, 7
 

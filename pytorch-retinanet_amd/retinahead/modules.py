@@ -383,7 +383,11 @@ class FocalLoss(nn.Module):
         fifth of what it costs alone.  The later ``forward`` with the same ``annotations`` tensor
         (unmodified), anchors, batch size and class count skips its assignment stage; any other
         call computes its own, so results never depend on this method.  Not used by
-        ``forward_levels`` or when a ``reduce_total`` hook stages the call."""
+        ``forward_levels`` or when a ``reduce_total`` hook stages the call.
+        Stream order: the kernel that carries the assignment reads ``annotations`` on the stream
+        of the next ``forward`` call, so the tensor must be complete on that stream by then -- an
+        upload made on a loader's side stream has to be ordered before it (``wait_stream`` /
+        an event), exactly as for a tensor passed to ``forward`` itself."""
         self.cfg["ahead"].ask(anchors, annotations, num_classes, self.cfg)
 
     @property
@@ -400,6 +404,9 @@ class FocalLoss(nn.Module):
 
     def _check_status(self):
         bits = int(self.last["status"].max().item())
+        if bits & _lib.RH_STATUS_REDUCTION_GAVE_UP:
+            raise RetinaHeadError("the loss reduction inside the stream launch gave up waiting for "
+                                  "a record (internal error; the losses of this call are NaN)")
         if bits & _lib.RH_STATUS_LABEL_RANGE:
             raise IndexError("annotation label outside [0, num_classes)")
         if bits & _lib.RH_STATUS_NONFINITE_BOX:

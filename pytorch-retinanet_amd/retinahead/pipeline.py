@@ -54,7 +54,9 @@ class PostprocessPipeline:
     ``iou_thresh``, ``mode``, ``pre_nms_topk``, ``max_det``, ``max_candidates``, ``from_logits``).
 
     A submitted batch's input tensors must stay unmodified until its results have been taken (the
-    kernels read them where they lie).  The outputs returned for a batch are views of buffers
+    kernels read them where they lie).  They must have been produced on the stream that is current
+    at ``submit`` (the slot's stream waits for that one, unless it is idle): work queued on any
+    other stream has to be ordered before the call by the caller.  The outputs returned for a batch are views of buffers
     that are reused ``depth`` submissions later: copy them if they are kept longer.  ``len(pipe)``
     is the number of batches submitted and not yet taken.
     """

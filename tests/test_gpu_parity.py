@@ -368,6 +368,7 @@ def test_loss_sum_uses_the_stored_total(rh, focal_golden):
     (2, 160, 601, 6, [6, 2], "per_image"),       # tiles cut into parts: several records per tile
     (70, 64, 8, 3, [3, 1, 0, 2], "per_image"),   # more images than a wave has lanes; N = 774, tiles straddle images
     (5, 96, 20, 4, [4, 1], "global"),
+    (150, 64, 5, 2, [2, 1, 0], "per_image"),     # more images than finishers may ride in a launch: own launch
 ])
 def test_final_reduction_inside_the_stream_launch(rh, bsz, size, c, m, valid, norm):
     """A call that runs the stream and the final reduction together reduces each image inside the

@@ -76,12 +76,13 @@ def test_static_nms_limits(rh):
     assert int(count.item()) == 0
 
 
-def test_static_nms_under_stream_capture(rh):
+@pytest.mark.parametrize("k", [1000, 4096])
+def test_static_nms_under_stream_capture(rh, k):
     """The reason the entry point exists: it can be captured into a hipGraph (after one call
-    outside capture has looked up the scratch address) and replayed on new data."""
+    outside capture has looked up the scratch address) and replayed on new data; also at the
+    entry point's limit, where the rank sort asks for more than the default share of LDS."""
     from retinahead import functional as F
     rng = np.random.default_rng(5)
-    k = 1000
     b_np, s_np, _ = make_boxes(rng, k, 600.0)
     b, s = torch.from_numpy(b_np).cuda(), torch.from_numpy(s_np).cuda()
     keep = torch.empty(k, dtype=torch.int64, device="cuda")
