@@ -544,8 +544,9 @@ __device__ __forceinline__ int gather_image_keys(const int j, const SortSrc src,
 //     plain NMS), with (rank or -1 when the box was cut by the top-k, label, bits of the box's
 //     float32 area, 0).  Neighbours in
 //     that order are neighbours in the image, which is what the pair kernel's culling needs;
-//   csum [(j*clusters + g)*2 ..]: for cluster g = list entries [64g, 64g + 64): the bounding box of
-//     its boxes that passed, then (smallest area, largest area, 0, 0).
+//   csum [(j*clusters + g)*3 ..]: for cluster g = list entries [64g, 64g + 64): the bounding box of
+//     its boxes that passed, then (smallest area, largest area, 0, 0), then the bounding box of
+//     their centres.
 //     All three are null when the sort path does not produce them;
 //   mask [j][w][r]: the predecessor words; the rank sort zeroes the words the NMS can touch.
 struct SortOut {
@@ -564,7 +565,9 @@ struct SortOut {
 // lane gets the result.  An empty cluster gets an inverted box that nothing intersects.
 struct ClusterSummary {
   float x1, y1, x2, y2, amin, amax;
+  float cx1, cy1, cx2, cy2;      // bounding box of the boxes' centres
 };
+constexpr int kSummaryVecs = 3;  // float4 per cluster: box, (area min, area max, 0, 0), centres' box
 __device__ __forceinline__ ClusterSummary summarize_cluster(const float4 b, const bool ok) {
   const float inf = __builtin_inff();
   const float area = (b.z - b.x) * (b.w - b.y);
@@ -575,6 +578,11 @@ __device__ __forceinline__ ClusterSummary summarize_cluster(const float4 b, cons
   c.y2 = wave_extreme<true>(ok ? b.w : -inf);
   c.amin = wave_extreme<false>(ok ? area : inf);
   c.amax = wave_extreme<true>(ok ? area : -inf);
+  const float cx = 0.5f * (b.x + b.z), cy = 0.5f * (b.y + b.w);
+  c.cx1 = wave_extreme<false>(ok ? cx : inf);
+  c.cy1 = wave_extreme<false>(ok ? cy : inf);
+  c.cx2 = wave_extreme<true>(ok ? cx : -inf);
+  c.cy2 = wave_extreme<true>(ok ? cy : -inf);
   return c;
 }
 
@@ -1102,9 +1110,10 @@ __device__ __forceinline__ void rank_pass(const int c0, const bool writes_counte
     if (cluster < so.clusters) {
       const ClusterSummary cs = summarize_cluster(box, passed);
       if (lane == 0) {
-        float4* out = so.csum + ((size_t)j * so.clusters + cluster) * 2;
+        float4* out = so.csum + ((size_t)j * so.clusters + cluster) * kSummaryVecs;
         out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
         out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
+        out[2] = make_float4(cs.cx1, cs.cy1, cs.cx2, cs.cy2);
       }
     }
     if (writes_counters && wave == 0 && lane == 0) {
@@ -1593,7 +1602,7 @@ __global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
   RH_TL(1, 0);
   const float4* bj = cbox + (size_t)j * list_stride;
   const int4* ij = cinfo + (size_t)j * list_stride;
-  const float4* sj = csum + (size_t)j * clusters * 2;
+  const float4* sj = csum + (size_t)j * clusters * kSummaryVecs;
   u64* mj = mask + (size_t)j * box_stride * wstride;
   u64* nj = nz + (size_t)j * box_stride * nzw;
   // My cluster's boxes and the summaries go out together with the counters (all inside their
@@ -1609,9 +1618,11 @@ __global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
     return r;
   };
   PairLane me = load_lane(min(A, clusters - 1));
-  float4 a_box = sj[min(A, clusters - 1) * 2], a_rng = sj[min(A, clusters - 1) * 2 + 1];   // uniform
+  float4 a_box = sj[min(A, clusters - 1) * kSummaryVecs], a_rng = sj[min(A, clusters - 1) * kSummaryVecs + 1];   // uniform
+  float4 a_ctr = sj[min(A, clusters - 1) * kSummaryVecs + 2];
   int first_b = min(A + lane, clusters - 1);
-  float4 b_box0 = sj[first_b * 2], b_rng0 = sj[first_b * 2 + 1];
+  float4 b_box0 = sj[first_b * kSummaryVecs], b_rng0 = sj[first_b * kSummaryVecs + 1];
+  float4 b_ctr0 = sj[first_b * kSummaryVecs + 2];
   __builtin_amdgcn_sched_barrier(0);
   // ranked: the list is what the rank sort saw; else the boxes are in rank order themselves
   // (list_len: the entries the rank sort was given -- all candidates found, or those the
@@ -1620,18 +1631,31 @@ __global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
   const int C = (klist + 63) >> 6;
   RH_TL(1, 1);
   const float f = fminf(thresh, 1.0f) * 0.9999f;
+  // From a threshold of one half on, an overlapping pair also has each box's centre inside the
+  // other box: IoU > 1/2 means the intersection covers more than half of either box's area, hence
+  // more than half of its width and of its height, and an interval that covers more than half of
+  // a segment contains the segment's midpoint.  The float32 quotient can exceed 1/2 when the
+  // exact one is 1e-6 short of it, and the midpoints are rounded: `slack` (a thousandth of the
+  // larger side of A's bounding box -- a box that overlaps one of A's by half is at most twice
+  // as wide -- or of its largest coordinate, whose rounding the midpoints carry) covers both.
+  const bool centre_rule = thresh >= 0.5f;
+  float slack = 0.0f;
   const float c_hi = thresh * (1.0f + 4.8e-7f);
   const float k_filter = thresh / (1.0f + thresh) * (1.0f - 1.9e-6f);
   for (; A < C; unit += unit_step, A = unit / slices, slice = unit % slices) {
   if (unit != (int)(blockIdx.x / batch)) {       // (the first unit's records were requested above)
     me = load_lane(A);
-    a_box = sj[A * 2];
-    a_rng = sj[A * 2 + 1];
+    a_box = sj[A * kSummaryVecs];
+    a_rng = sj[A * kSummaryVecs + 1];
+    a_ctr = sj[A * kSummaryVecs + 2];
     first_b = min(A + lane, clusters - 1);
-    b_box0 = sj[first_b * 2];
-    b_rng0 = sj[first_b * 2 + 1];
+    b_box0 = sj[first_b * kSummaryVecs];
+    b_rng0 = sj[first_b * kSummaryVecs + 1];
+    b_ctr0 = sj[first_b * kSummaryVecs + 2];
   }
   if (A * 64 + lane >= klist) me.rank = -1;
+  slack = 1e-3f * fmaxf(fmaxf(a_box.z - a_box.x, a_box.w - a_box.y),
+                        fmaxf(fmaxf(fabsf(a_box.x), fabsf(a_box.y)), fmaxf(fabsf(a_box.z), fabsf(a_box.w))));
 
   const float4 mine = me.box;
   const float area = me.area;
@@ -1687,9 +1711,15 @@ __global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
   for (int b0 = A; b0 < C; b0 += 64) {
     // ---- cluster test, 64 clusters per ballot (the first 64 summaries were requested up front)
     const int bc = min(b0 + lane, C - 1);
-    const float4 b_box = b0 == A ? b_box0 : sj[bc * 2], b_rng = b0 == A ? b_rng0 : sj[bc * 2 + 1];
-    const bool apart_c = (b_box.z <= a_box.x) | (b_box.x >= a_box.z) | (b_box.w <= a_box.y) |
-                         (b_box.y >= a_box.w);
+    const float4 b_box = b0 == A ? b_box0 : sj[bc * kSummaryVecs], b_rng = b0 == A ? b_rng0 : sj[bc * kSummaryVecs + 1];
+    const float4 b_ctr = b0 == A ? b_ctr0 : sj[bc * kSummaryVecs + 2];
+    bool apart_c = (b_box.z <= a_box.x) | (b_box.x >= a_box.z) | (b_box.w <= a_box.y) |
+                   (b_box.y >= a_box.w);
+    // centre rule: some centre of B must lie in A's bounding box and some centre of A in B's
+    if (centre_rule)
+      apart_c |= (b_ctr.z < a_box.x - slack) | (b_ctr.x > a_box.z + slack) | (b_ctr.w < a_box.y - slack) |
+                 (b_ctr.y > a_box.w + slack) | (a_ctr.z < b_box.x - slack) | (a_ctr.x > b_box.z + slack) |
+                 (a_ctr.w < b_box.y - slack) | (a_ctr.y > b_box.w + slack);
     const bool off_c = (b_rng.x * f > a_rng.y) | (b_rng.y < a_rng.x * f);   // all too large / too small
     u64 bm = __ballot(b0 + lane < C && !apart_c && !off_c);
     // A unit of work is half a cluster pair (32 of B's boxes), dealt round robin over the waves
@@ -1713,14 +1743,23 @@ __global__ __launch_bounds__(kPairThreads) void nms_pairs_kernel(
       if (my_bm != 0ull) nxt = load_lane(b0 + __builtin_ctzll(my_bm));   // on its way meanwhile
       // B's boxes one per lane, only to find the ones worth testing: a box that misses A's
       // bounding box or area range is out (a NaN coordinate is never culled, and never hits)
-      const bool apart = (e.box.z <= a_box.x) | (e.box.x >= a_box.z) | (e.box.w <= a_box.y) |
-                         (e.box.y >= a_box.w);
+      const float ecx = 0.5f * (e.box.x + e.box.z), ecy = 0.5f * (e.box.y + e.box.w);
+      bool apart = (e.box.z <= a_box.x) | (e.box.x >= a_box.z) | (e.box.w <= a_box.y) |
+                   (e.box.y >= a_box.w);
+      if (centre_rule) {      // the box's centre in A's bounding box, a centre of A in the box
+        apart |= (ecx < a_box.x - slack) | (ecx > a_box.z + slack) | (ecy < a_box.y - slack) |
+                 (ecy > a_box.w + slack) | (a_ctr.z < e.box.x - slack) | (a_ctr.x > e.box.z + slack) |
+                 (a_ctr.w < e.box.y - slack) | (a_ctr.y > e.box.w + slack);
+      }
       const bool off = (e.area * f > a_rng.y) | (e.area < a_rng.x * f);
       const bool there = B * 64 + lane < klist && e.rank >= 0;
       const u64 hm = __ballot(there && !apart && !off) & halves;
       RH_TL_DO(++tl_tiles; tl_surv += __popcll(hm); tl_t = wall_clock64();)
       // The survivors one at a time as wave-uniform values, broadcast from their lanes
-      // (v_readlane), four per round.  Measured alternatives: packing them into LDS and reading
+      // (v_readlane), four per round.  Measured alternatives: testing first, per round, whether any
+      // lane's box contains a survivor's centre (two broadcasts and five instructions per box
+      // instead of the overlap arithmetic) rejects almost no round -- among 4 x 64 pairs of one
+      // strip of the image some lane nearly always does -- and cost 2 us per call; packing them into LDS and reading
       // them back with 16-byte broadcast reads was bound by the LDS pipe, which all waves of a
       // compute unit share (a broadcast read costs the bandwidth of 64 lanes).  (A variant with
       // hand-written scalar loads of the same records once gave wrong keep lists; scalar loads of
@@ -1785,9 +1824,10 @@ __global__ __launch_bounds__(64) void cluster_prepare_kernel(const float4* __res
   const float4 box = sbox[(size_t)j * box_stride + min(i, K - 1)];
   const ClusterSummary cs = summarize_cluster(box, i < K);
   if (lane == 0) {
-    float4* out = csum + ((size_t)j * clusters + g) * 2;
+    float4* out = csum + ((size_t)j * clusters + g) * kSummaryVecs;
     out[0] = make_float4(cs.x1, cs.y1, cs.x2, cs.y2);
     out[1] = make_float4(cs.amin, cs.amax, 0.f, 0.f);
+    out[2] = make_float4(cs.cx1, cs.cy1, cs.cx2, cs.cy2);
   }
   if (i < K) {
     cinfo[(size_t)j * box_stride + i] =
@@ -2185,7 +2225,7 @@ struct PostWorkspace {
   u64* nz;           // [B][box_cap][nzw] which words those are
   float4* cbox;      // [B][cap] boxes in list order (rank sort only)
   int4* cinfo;       // [B][cap] (rank or -1, label) in list order (rank sort only)
-  float4* csum;      // [B][clusters][2] bounding box and area range of each cluster
+  float4* csum;      // [B][clusters][3] bounding box, area range and centres' box of each cluster
   u64* sel_key;      // [B][cap] keys kept by the top-k pre-selection, their labels, their number
   int* sel_lab;
   int* sel_count;
@@ -2207,7 +2247,7 @@ static PostWorkspace carve_post(void* ws, const NmsPlan& p, long long num_tiles)
   w.nz = cv.take<u64>((size_t)p.batch * p.box_cap * p.nzw);
   w.cbox = cv.take<float4>(p.ranked ? (size_t)p.batch * p.cap : 0);
   w.cinfo = cv.take<int4>((size_t)p.batch * (p.ranked ? p.cap : p.box_cap));
-  w.csum = cv.take<float4>((size_t)p.batch * p.clusters * 2);
+  w.csum = cv.take<float4>((size_t)p.batch * p.clusters * kSummaryVecs);
   w.sel_key = cv.take<u64>(p.select ? (size_t)p.batch * p.cap : 0);
   w.sel_lab = cv.take<int>(p.select ? (size_t)p.batch * p.cap : 0);
   w.sel_count = cv.take<int>(p.select ? (size_t)p.batch : 0);

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--shape", help="B,size,C,M instead of --cfg")
     ap.add_argument("--topk", type=int, default=0, help="pre-NMS top-k (post-processing)")
     ap.add_argument("--cap", type=int, default=4096, help="candidate capacity per image (post-processing)")
+    ap.add_argument("--mu", type=float, default=-7.0, help="mean of the inference logits (post-processing)")
     a = ap.parse_args()
     bsz, size, c, m = [int(x) for x in a.shape.split(",")] if a.shape else CFG[a.cfg]
     dev = torch.device("cuda:0")
@@ -98,7 +99,7 @@ def main():
             assert torch.equal(ref["losses"], outs[0]["losses"]) and torch.equal(ref["losses"], outs[1]["losses"])
             assert torch.equal(ref["d_classifications"], outs[0]["d_classifications"])
     else:
-        icls_np, ireg_np = bench.synth_infer(rng, bsz, n, c)
+        icls_np, ireg_np = bench.synth_infer(rng, bsz, n, c, a.mu)
         icls, ireg = torch.from_numpy(icls_np).to(dev), torch.from_numpy(ireg_np).to(dev)
         if a.levels:
             shapes = [((size + 2 ** l - 1) // 2 ** l,) * 2 for l in (3, 4, 5, 6, 7)]
