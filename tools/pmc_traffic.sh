@@ -24,7 +24,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] == ctr and "focal_stream_kernel" in r["Kernel_Name"]:
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     vals[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
-    with open(f"{out}/r02_pmc_{ctr.lower()}.txt", "w") as fh:
+    with open(f"{out}/r03_pmc_{ctr.lower()}.txt", "w") as fh:
         for k, (m, n) in sorted(vals[ctr].items()):
             fh.write(f"{k}: {ctr} mean {m:.2f} KiB over {n} launches\n")
 algo = bench.BATCH * 69354 * (8 * bench.CLASSES + 48)
