@@ -75,16 +75,37 @@ __device__ __forceinline__ float iou_pair(const float4 a, const float area_a, co
 #endif
 constexpr int kAssignPer = RH_ASSIGN_PER;   // anchors per thread
 constexpr int kAssignBlock = kThreads * kAssignPer;   // anchors per block
-// Long annotation lists (more than kSplitRows rows per image) take the split form of the kernel:
-// the four waves of a block share one wave's worth of anchors and each scans every fourth
-// 64-row chunk of the list, so the serial walk over the boxes that survive the cull -- on the
-// coarse pyramid levels nearly all of them -- is a quarter as long; the waves' maxima are merged
-// through LDS (larger IoU first, then lower GT index: the first arg-max).
-constexpr int kSplitRows = 128;
-constexpr int kSplitAnchors = 64 * kAssignPer;
-static inline bool assign_split(int m) { return m > kSplitRows; }
-static inline int assign_blocks(long long n, int m) {
-  const int per = assign_split(m) ? kSplitAnchors : kAssignBlock;
+// Long annotation lists take the split form of the kernel: the four waves of a block share one
+// wave's worth of anchors and each scans every fourth 64-row chunk of the list, so the serial
+// walk over the boxes that survive the cull -- on the coarse pyramid levels nearly all of them --
+// is a quarter as long; the waves' maxima are merged through LDS (larger IoU first, then lower GT
+// index: the first arg-max).  "Long" is more than kSplitRows rows when the maximum IoU, arg-max or
+// state of every anchor is wanted (rh_assign); when only the loss's packed codes are, boxes that
+// cannot reach the lower threshold with any anchor of the wave are culled as well, few survive
+// even on the coarse levels, and the plain form stays the faster one up to kSplitRowsCodes rows
+// (4 x 196 416 anchors, 256 boxes per image: assignment 18.7 us split against 13.1 plain, the
+// step that carries it 111.6 against 96.6 us; 600 boxes: 113 against 110; 1500: 79 against 89).
+#ifndef RH_SPLIT_ROWS
+#define RH_SPLIT_ROWS 128
+#endif
+#ifndef RH_SPLIT_ROWS_CODES
+#define RH_SPLIT_ROWS_CODES 1024
+#endif
+constexpr int kSplitRows = RH_SPLIT_ROWS;
+constexpr int kSplitRowsCodes = RH_SPLIT_ROWS_CODES;
+// Anchors per thread in the split form: six make a third as many workgroups as two, each paying
+// the walk over the annotation rows once (256 boxes per image: 18.7 -> 16.2 us, the carrying step
+// 111.6 -> 100.3 us; eight spill inside the stream kernel's 96 registers).
+#ifndef RH_SPLIT_PER
+#define RH_SPLIT_PER 6
+#endif
+constexpr int kSplitPer = RH_SPLIT_PER;
+constexpr int kSplitAnchors = 64 * kSplitPer;
+static inline bool assign_split(int m, bool codes_only) {
+  return m > (codes_only ? kSplitRowsCodes : kSplitRows);
+}
+static inline int assign_blocks(long long n, bool split) {
+  const int per = split ? kSplitAnchors : kAssignBlock;
   return (int)((n + per - 1) / per);
 }
 
@@ -163,6 +184,7 @@ template <bool kSplit>
 __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, const int bx,
                                              const int nblk) {
   __shared__ int s_cnt[kThreads / 64];
+  constexpr int kPer = kSplit ? kSplitPer : kAssignPer;     // anchors per thread
   constexpr int kShare = kSplit ? kSplitAnchors : 1;
   __shared__ float s_best[kThreads / 64][kShare];
   __shared__ int s_bidx[kThreads / 64][kShare];
@@ -197,11 +219,11 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
   const float* aj = ann + (size_t)j * M * 5;
   const bool publisher = bx == 0 && wave == 0;
 
-  float4 a[kAssignPer];
-  float area_a[kAssignPer], best[kAssignPer];
-  int best_idx[kAssignPer], best_lab[kAssignPer];
+  float4 a[kPer];
+  float area_a[kPer], best[kPer];
+  int best_idx[kPer], best_lab[kPer];
 #pragma unroll
-  for (int k = 0; k < kAssignPer; ++k) {
+  for (int k = 0; k < kPer; ++k) {
     // lanes past the last anchor repeat it: their results are not stored, and the wave's
     // bounding box stays what the real anchors make it
     a[k] = anchors[min(base + k * kStride, N - 1)];
@@ -209,7 +231,7 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
   AnnRow next = M > 0 ? load_row(aj, lane, M) : AnnRow{0.f, 0.f, 0.f, 0.f, -1.0f};
   float lo_x = a[0].x, lo_y = a[0].y, hi_x = a[0].z, hi_y = a[0].w;
 #pragma unroll
-  for (int k = 0; k < kAssignPer; ++k) {
+  for (int k = 0; k < kPer; ++k) {
     area_a[k] = (a[k].z - a[k].x) * (a[k].w - a[k].y);
     best[k] = 0.0f;   // every IoU is >= 0, so "first maximum" starts at (0, index 0)
     best_idx[k] = 0;
@@ -237,7 +259,7 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
   if (!state && !argmax && !label && !iou_max) {
     float amin = area_a[0], amax = area_a[0];
 #pragma unroll
-    for (int k = 1; k < kAssignPer; ++k) {
+    for (int k = 1; k < kPer; ++k) {
       amin = vmin(amin, area_a[k]);
       amax = vmax(amax, area_a[k]);
     }
@@ -301,21 +323,21 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
                                    lane_value(r.x2, src), lane_value(r.y2, src));
       const int gi = cnt + __popcll(vm & ((1ull << src) - 1ull));
       // overlap test for the thread's anchors first; one (rare) branch per GT box
-      float iw[kAssignPer], ih[kAssignPer], mm[kAssignPer];
+      float iw[kPer], ih[kPer], mm[kPer];
 #pragma unroll
-      for (int k = 0; k < kAssignPer; ++k) {
+      for (int k = 0; k < kPer; ++k) {
         iw[k] = vmin(a[k].z, b.z) - vmax(a[k].x, b.x);
         ih[k] = vmin(a[k].w, b.w) - vmax(a[k].y, b.y);
         mm[k] = vmin(iw[k], ih[k]);
       }
       float any = mm[0];
 #pragma unroll
-      for (int k = 1; k < kAssignPer; ++k) any = vmax(any, mm[k]);
+      for (int k = 1; k < kPer; ++k) any = vmax(any, mm[k]);
       if (any > 0.0f) {
         const float ab = lane_value(rarea, src);
         const int lb = __builtin_amdgcn_readlane(li, src);
 #pragma unroll
-        for (int k = 0; k < kAssignPer; ++k) {
+        for (int k = 0; k < kPer; ++k) {
           if (mm[k] > 0.0f) {
             // losses.py:12-21 (iw, ih > 0 here, so the clamps at 0 are no-ops)
             const float inter = iw[k] * ih[k];
@@ -343,7 +365,7 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
     // merge the waves' results: larger IoU wins, equal IoU goes to the lower GT index (a wave
     // that found nothing holds IoU 0 at index 0, which only a positive IoU displaces)
 #pragma unroll
-    for (int k = 0; k < kAssignPer; ++k) {
+    for (int k = 0; k < kPer; ++k) {
       s_best[wave][lane + k * 64] = best[k];
       s_bidx[wave][lane + k * 64] = best_idx[k];
       s_blab[wave][lane + k * 64] = best_lab[k];
@@ -351,7 +373,7 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int k = 0; k < kAssignPer; ++k) {
+    for (int k = 0; k < kPer; ++k) {
 #pragma unroll
       for (int w = 1; w < kThreads / 64; ++w) {
         const float v = s_best[w][lane + k * 64];
@@ -367,7 +389,7 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
 
   int npos = 0;
 #pragma unroll
-  for (int k = 0; k < kAssignPer; ++k) {
+  for (int k = 0; k < kPer; ++k) {
     const int n = base + k * kStride;
     int st, cd, lb = -1;
     if (cnt == 0) {
@@ -1525,6 +1547,7 @@ struct LossWorkspace {
   int* gt_count;
   int* blk_pos;      // [B][assign blocks per image]
   int nblk;
+  bool split;        // form of the assignment kernel that fills blk_pos (nblk follows from it)
   int* code;
   float* partials;
   long long partial_count;   // floats
@@ -1557,7 +1580,8 @@ static LossWorkspace carve_loss(void* ws, int batch, long long n, int c, int m) 
   LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = assign_blocks(n, m);
+  w.split = assign_split(m, true);      // the loss wants the codes only
+  w.nblk = assign_blocks(n, w.split);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partial_count = partial_floats(batch, n, c);
@@ -1617,7 +1641,7 @@ static int launch_assign(const float* anchors, const float* annotations, int bat
                          hipStream_t s, const CodeLayout& lay = CodeLayout{}) {
   RH_REQUIRE(w.nblk <= 65535, RH_ESHAPE, "n=%lld with m=%d: more than 65535 assignment blocks per image", n, m);
   dim3 grid((unsigned)batch, (unsigned)w.nblk);
-  hipLaunchKernelGGL(assign_split(m) ? assign_kernel<true> : assign_kernel<false>, grid, dim3(kThreads), 0, s,
+  hipLaunchKernelGGL(w.split ? assign_kernel<true> : assign_kernel<false>, grid, dim3(kThreads), 0, s,
                      assign_args(anchors, annotations, batch, n, m, c, neg_t, pos_t, w, code, state, argmax,
                                  label, iou_max, status, lay));
   RH_CHECK_LAUNCH("assign_kernel");
@@ -1672,7 +1696,8 @@ static LossWorkspace carve_levels(void* ws, int batch, long long n, int m, long 
   LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = assign_blocks(n, m);
+  w.split = assign_split(m, true);
+  w.nblk = assign_blocks(n, w.split);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.code = cv.take<int>((size_t)batch * n);
   w.partials = cv.take<float>((size_t)batch * blocks * 2);
@@ -1756,7 +1781,8 @@ static LossWorkspace carve_assign(void* ws, int batch, long long n, int m) {
   LossWorkspace w{};
   w.gt = cv.take<GtRec>((size_t)batch * (m > 0 ? m : 1));
   w.gt_count = cv.take<int>(batch);
-  w.nblk = assign_blocks(n, m);
+  w.split = assign_split(m, false);
+  w.nblk = assign_blocks(n, w.split);
   w.blk_pos = cv.take<int>((size_t)batch * w.nblk);
   w.bytes = cv.off;
   return w;
@@ -1912,7 +1938,7 @@ int rh_focal_loss_fwd_bwd_ahead(const float* classifications, const float* regre
         ahead_blocks = batch * wn.nblk;
         next_assigned = true;
       }
-      const int form = !ride ? 0 : (assign_split(next->m) ? 2 : 1);
+      const int form = !ride ? 0 : (wn.split ? 2 : 1);
       typedef decltype(&focal_stream_kernel<5, false, 0>) StreamKernel;
       static const StreamKernel table[2][2][3] = {
           {{focal_stream_kernel<4, false, 0>, focal_stream_kernel<4, false, 1>, focal_stream_kernel<4, false, 2>},

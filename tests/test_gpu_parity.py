@@ -84,11 +84,13 @@ def test_assign_and_loss_golden(rh, focal_golden, case):
     grad_close(reg.grad.cpu().numpy(), d["d_reg"], atol_rel=REG_ATOL_REL, kind="d_reg")
 
 
-@pytest.mark.parametrize("m", [1, 63, 64, 65, 130, 300])
+@pytest.mark.parametrize("m", [1, 63, 64, 65, 130, 300, 1100])
 def test_assign_ragged_annotation_rows(rh, m):
     """Valid rows scattered among padding rows, lists longer than one 64-row chunk, chunks
     without any valid row, boxes outside the image and degenerate boxes: states, arg-max (index
-    into the valid list), labels, IoU maxima and counts bit for bit."""
+    into the valid list), labels, IoU maxima and counts bit for bit.  (The assignment kernel has
+    a plain and a split form; rh_assign takes the split one above 128 rows, the loss, which wants
+    the codes only, above 1024.)"""
     rng = np.random.default_rng(500 + m)
     size, c, bsz = 160, 7, 4
     anc = O.anchors_for_image(size, size)
@@ -181,6 +183,7 @@ def make_batch(seed, bsz, size, c, m, valid):
     (2, 96, 5, 4, [4, 1]),           # C not a multiple of 4
     (1, 64, 3, 4, [3]),              # C < 4: generic row kernel
     (2, 320, 80, 256, [256, 100]),   # dense GT, several LDS chunks
+    (2, 160, 20, 1100, [1100, 300]), # a list long enough for the split form of the assignment
 ])
 def test_loss_vs_oracle(rh, bsz, size, c, m, valid):
     cls, reg, anc, ann = make_batch(7 + c, bsz, size, c, m, valid)

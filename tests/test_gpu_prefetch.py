@@ -43,9 +43,10 @@ def stages_seen(rh, monkeypatch):
     return seen
 
 
-@pytest.mark.parametrize("normalizer,m", [("per_image", 6), ("global", 6), ("per_image", 200)])
+@pytest.mark.parametrize("normalizer,m", [("per_image", 6), ("global", 6), ("per_image", 200),
+                                          ("per_image", 1100)])
 def test_prefetched_assignment_gives_the_plain_step(rh, stages_seen, normalizer, m):
-    """m = 200: annotation lists long enough for the split form of the assignment kernel (four
+    """m = 1100: annotation lists long enough for the split form of the assignment kernel (four
     waves share a block's anchors), which rides on the stream launch like the plain form."""
     size, c = 160, 20
     batches = [make_batch(50 + i, 3, size, c, m, [m, 0, 2]) for i in range(4)]

@@ -15,6 +15,9 @@ import bench  # noqa: E402
 import retinahead as rh  # noqa: E402
 from retinahead import _lib, functional as F  # noqa: E402
 
+if os.environ.get("RH_LIB"):        # another build of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RH_LIB"])
+
 CFG = {5: (128, 256, 80, 20), 1: (16, 512, 80, 20), 2: (16, 608, 80, 20), 3: (8, 800, 601, 8), 4: (4, 1024, 80, 256)}
 
 
@@ -97,6 +100,16 @@ def main():
                   f"  algo {algo / mean / 1e6:8.1f} GB/s = {algo / mean / 1e6 / 8000:.3f} of the HBM peak")
             ref = F.focal_loss_fwd_bwd(cls, reg, anchors, ann)
             assert torch.equal(ref["losses"], outs[0]["losses"]) and torch.equal(ref["losses"], outs[1]["losses"])
+            # the step of a loop that cannot announce: the assignment's launch, then the stream's
+            plain = lambda: F.focal_loss_fwd_bwd(cls, reg, anchors, ann, out=bufs)
+            for _ in range(10):
+                plain()
+            mean, mn = bench.event_train(plain, 20, 10)
+            print(f"step, no look-ahead, two launches: mean {mean * 1e3:8.1f} us  best train {mn * 1e3:8.1f} us"
+                  f"  = {algo / mean / 1e6 / 8000:.3f} of the HBM peak")
+            asg = lambda: F.focal_loss_fwd_bwd(cls, reg, anchors, ann, stages=_lib.STAGE_ASSIGN, out=bufs)
+            mean, mn = bench.event_train(asg, 20, 10)
+            print(f"assignment launches back to back: mean {mean * 1e3:8.1f} us")
             assert torch.equal(ref["d_classifications"], outs[0]["d_classifications"])
     else:
         icls_np, ireg_np = bench.synth_infer(rng, bsz, n, c, a.mu)
