@@ -654,7 +654,7 @@ def main():
     for cand in stream_sets[1:]:
         streams = cand
         trial.append(piped(post_on))
-        trial_same.append(piped(lambda i: post, rounds=50))
+        trial_same.append(piped(lambda i: post))
     piped_ms = float(np.median(trial))
     piped_same_ms = float(np.median(trial_same))
     trial_p10, trial_p90 = (float(np.percentile(trial, q)) for q in (10, 90))
