@@ -66,6 +66,19 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// K sums at once, step by step: the K exchanges of a step are independent and go out together
+// (one wait per step instead of one per exchange); each sum is the butterfly of wave_sum().
+template <int K>
+__device__ __forceinline__ void wave_sum_many(double (&v)[K]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double t[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) t[a] = __shfl_xor(v[a], o, 64);
+#pragma unroll
+    for (int a = 0; a < K; ++a) v[a] += t[a];
+  }
+}
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

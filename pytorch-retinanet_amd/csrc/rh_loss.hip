@@ -653,6 +653,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red /*[4]*/) {
 // each carries the call's tag.
 // ---------------------------------------------------------------------------
 constexpr int kFinalBatch = 8;
+#ifndef RH_FINAL_KERNEL_BATCH
+#define RH_FINAL_KERNEL_BATCH 12
+#endif
+constexpr int kFinalKernelBatch = RH_FINAL_KERNEL_BATCH;   // finalize_kernel has registers for more loads in flight
 constexpr int kFinishSpins = 1 << 21;
 constexpr int kMaxFinishers = 128;      // finishing workgroups inside a stream launch   // about two seconds of polling before giving up
 struct ImageLoss {
@@ -739,7 +743,18 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
             qr[k] = atoms[at + 1];
           }
         }
-        if (!kCoherent) break;
+        // every load of the round is requested before the first one is used (left to itself the
+        // scheduler pairs each load with its additions to save registers: a memory latency per
+        // pair instead of one per round)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!kCoherent) {
+          // (the tag halves are not read here; were they dead, the register allocator would hand
+          // them to the next load's address arithmetic, which then waits for the load in flight
+          // into them: a memory latency per pair of loads.  The empty statement keeps them alive.)
+#pragma unroll
+          for (int k = 0; k < kBatch; ++k) asm volatile("" ::"v"(qc[k]), "v"(qr[k]));
+          break;
+        }
         // written during this launch: wait until every atom carries the call's tag
         bool all_in = true;
 #pragma unroll
@@ -792,16 +807,25 @@ __device__ __forceinline__ ImageLoss finalize_image(const FinalIn& f, const int 
   np = wave_sum(np);
   double ct, rt;
   if (kWaves == 1) {
+    double both[2 * kAcc];
 #pragma unroll
     for (int a = 0; a < kAcc; ++a) {
-      c[a] = wave_sum(c[a]);
-      r[a] = wave_sum(r[a]);
+      both[a] = c[a];
+      both[kAcc + a] = r[a];
+    }
+    wave_sum_many(both);
+#pragma unroll
+    for (int a = 0; a < kAcc; ++a) {
+      c[a] = both[a];
+      r[a] = both[kAcc + a];
     }
     ct = (c[0] + c[kAcc > 1 ? 1 : 0]) + (c[kAcc > 2 ? 2 : 0] + c[kAcc > 3 ? 3 : 0]);
     rt = (r[0] + r[kAcc > 1 ? 1 : 0]) + (r[kAcc > 2 ? 2 : 0] + r[kAcc > 3 ? 3 : 0]);
   } else {
     // one share per wave: combined through LDS (s_fin: 2 * kFinalShares + 1 doubles)
-    const double cw = wave_sum(c[0]), rw = wave_sum(r[0]);
+    double both[2] = {c[0], r[0]};
+    wave_sum_many(both);
+    const double cw = both[0], rw = both[1];
     const bool any_out = __ballot(timed_out) != 0ull;
     __syncthreads();
     if (lane == 0) {
@@ -860,7 +884,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalize_kernel(const FinalIn f
   for (int j0 = 0; j0 < f.B; j0 += kFinalThreads / 64) {
     const int j = j0 + wave;
     ImageLoss il{0.f, 0.f, 0};
-    if (j < f.B) il = finalize_image<false, kFinalBatch, 1>(f, j, nullptr);
+    if (j < f.B) il = finalize_image<false, kFinalKernelBatch, 1>(f, j, nullptr);
     __syncthreads();
     if (lane == 0) {
       s_img[0][wave] = il.cl;

@@ -7,6 +7,10 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-retinanet_amd")):
 import bench
 import retinahead as rh
 from retinahead import _lib, functional as F
+if os.environ.get("RH_LIB"):        # another build of the library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RH_LIB"])
+if len(sys.argv) > 1:               # B,size,C,M instead of the benchmark's shape
+    bench.BATCH, bench.SIZE, bench.CLASSES, bench.MAX_GT = (int(v) for v in sys.argv[1].split(","))
 dev = torch.device("cuda", 0)
 anchors = rh.Anchors()(torch.zeros(1, 3, bench.SIZE, bench.SIZE, device=dev))
 n = anchors.shape[1]
