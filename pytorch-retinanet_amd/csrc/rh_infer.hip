@@ -1992,6 +1992,11 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
   int olab[kCached];
   if (kSlots > 0) {
     u64 bits[kCached];
+    // (no load below sits behind a condition of its own -- labels are read through a pointer
+    // that is always valid, absent words from word 0 and masked out afterwards: a load inside a
+    // branch is followed by a wait for EVERYTHING in flight where the branch ends, which made
+    // the slots' requests take a memory latency each instead of one together)
+    const int* lj_any = lj ? lj : reinterpret_cast<const int*>(kj);
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
       // The first two slots (2 048 boxes) are requested beside the load of K, rows clamped by
@@ -2003,7 +2008,7 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
         bits[s] = nj[(size_t)row * nzw];
         okey[s] = kj[row];
         obox[s] = bj[row];
-        olab[s] = lj ? lj[row] : 0;
+        olab[s] = lj_any[row];
       } else {
         bits[s] = 0ull;
         okey[s] = 0ull;
@@ -2011,6 +2016,9 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
         olab[s] = 0;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    u64 x[kCached], y[kCached];
+    bool has0[kCached], has1[kCached];
 #pragma unroll
     for (int s = 0; s < kCached; ++s) {
       const int c = s * kResolveWaves + wave;
@@ -2020,20 +2028,27 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       // a box without predecessor words is kept: the first round is done here
       const u64 free_now = __ballot(live && b == 0ull);
       if (c < W && lane == 0) s_lo[c] = free_now;
-      const bool has0 = b != 0ull;
-      pr[s].i0 = has0 ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
+      has0[s] = b != 0ull;
+      pr[s].i0 = has0[s] ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
       b &= b - 1ull;
-      const bool has1 = b != 0ull;
-      pr[s].i1 = has1 ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
+      has1[s] = b != 0ull;
+      pr[s].i1 = has1[s] ? min((int)__builtin_ctzll(b), wstride - 1) : 0;
       b &= b - 1ull;
       pr[s].more = b != 0ull;
-      u64 x = 0ull, y = 0ull;
+      x[s] = y[s] = 0ull;
       if (s < 2 || c < W) {
-        x = mj[(size_t)pr[s].i0 * box_stride + row];
-        y = mj[(size_t)pr[s].i1 * box_stride + row];
+        x[s] = mj[(size_t)pr[s].i0 * box_stride + row];
+        y[s] = mj[(size_t)pr[s].i1 * box_stride + row];
       }
-      pr[s].w0 = has0 ? x & earlier_bits(pr[s].i0, c * 64 + lane) : 0ull;
-      pr[s].w1 = has1 ? y & earlier_bits(pr[s].i1, c * 64 + lane) : 0ull;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < kCached; ++s) {
+      const int c = s * kResolveWaves + wave;
+      // (a mask, not a conditional: a value that is only used under a condition lets the compiler
+      // move its load under that condition too)
+      pr[s].w0 = x[s] & earlier_bits(pr[s].i0, c * 64 + lane) & (has0[s] ? ~0ull : 0ull);
+      pr[s].w1 = y[s] & earlier_bits(pr[s].i1, c * 64 + lane) & (has1[s] ? ~0ull : 0ull);
     }
   }
   __syncthreads();
