@@ -1966,10 +1966,6 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
   const int* lj = slabel ? slabel + (size_t)j * box_stride : nullptr;
   const u64* mj = mask + (size_t)j * box_stride * wstride;
   const u64* nj = nz + (size_t)j * box_stride * nzw;
-  if (threadIdx.x == 0) {
-    if (o.cand_out) o.cand_out[j] = o.counters[j];
-    if (o.ovf_out) o.ovf_out[j] = o.counters[o.batch + j];
-  }
   constexpr int kCached = kSlots > 0 ? kSlots : 1;
   const int nslots = kSlots > 0 ? kSlots : (W + kResolveWaves - 1) / kResolveWaves;
 
@@ -2164,6 +2160,12 @@ __global__ __launch_bounds__(kResolveThreads) void nms_resolve_kernel(
       const int row = min(c * 64 + lane, K - 1);
       emit(c, kj[row], bj[row], lj ? lj[row] : 0);
     }
+  }
+  // (at the end: their counters come by dependent scalar loads, which at the start of the
+  // kernel held wave 0 back from its first requests)
+  if (threadIdx.x == kResolveThreads - 1) {
+    if (o.cand_out) o.cand_out[j] = o.counters[j];
+    if (o.ovf_out) o.ovf_out[j] = o.counters[o.batch + j];
   }
   RH_TL(2, 3);
 }

@@ -206,13 +206,6 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
   RH_MARK(0);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (aa.clear_a) {       // this block's share of the record atoms, interleaved by thread
-    const long long step = (long long)aa.batch * nblk * kThreads;
-    for (long long i = ((long long)j * nblk + bx) * kThreads + threadIdx.x; i < aa.clear_a_count; i += step)
-      aa.clear_a[i] = 0ull;
-    if (bx == 0 && j == 0)
-      for (int i = threadIdx.x; i < aa.clear_b_count; i += kThreads) aa.clear_b[i] = 0ull;
-  }
   // anchors of thread t: base + k * stride.  Split form: every wave holds the same anchors.
   constexpr int kStride = kSplit ? 64 : kThreads;
   const int base = kSplit ? bx * kSplitAnchors + lane : bx * kAssignBlock + (int)threadIdx.x;
@@ -229,6 +222,16 @@ __device__ __forceinline__ void assign_block(const AssignArgs& aa, const int j, 
     a[k] = anchors[min(base + k * kStride, N - 1)];
   }
   AnnRow next = M > 0 ? load_row(aj, lane, M) : AnnRow{0.f, 0.f, 0.f, 0.f, -1.0f};
+  // (after the requests above, not before: the clearing's own kernel arguments arrive by scalar
+  // loads that would otherwise stand between the start of the block and its first request)
+  __builtin_amdgcn_sched_barrier(0);
+  if (aa.clear_a) {       // this block's share of the record atoms, interleaved by thread
+    const long long step = (long long)aa.batch * nblk * kThreads;
+    for (long long i = ((long long)j * nblk + bx) * kThreads + threadIdx.x; i < aa.clear_a_count; i += step)
+      aa.clear_a[i] = 0ull;
+    if (bx == 0 && j == 0)
+      for (int i = threadIdx.x; i < aa.clear_b_count; i += kThreads) aa.clear_b[i] = 0ull;
+  }
   float lo_x = a[0].x, lo_y = a[0].y, hi_x = a[0].z, hi_y = a[0].w;
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
