@@ -182,6 +182,31 @@ def test_postprocess_full_size(rh, mode, topk, shape):
     assert np.array_equal(res[b]["boxes"].cpu().numpy(), bo)
 
 
+@pytest.mark.parametrize("mode", ["agnostic", "per_class"])
+def test_postprocess_one_image_608(rh, mode):
+    """The call shape of the reference's inference scripts (visualize.py:95, evaluate.py:95,
+    csv_eval.py:89, coco_eval.py:27): ONE 608 px image per call on one stream, here two different
+    images through the same call twice each (buffers of the first call are reused by the later
+    ones).  Scores, labels and boxes against the oracle bit for bit, fed with the device's own
+    decoded boxes; and the same detections as the image gets inside a batch of 16."""
+    size, c = 608, 80
+    cls, reg, anchors = infer_inputs(rh, 16, size, c, seed=5)
+    batch = rh.postprocess(cls, reg, anchors, (size, size), mode=mode)
+    boxes_all = rh.ClipBoxes()(rh.BBoxTransform()(anchors, reg), torch.zeros(1, 3, size, size, device="cuda"))
+    for rep in range(2):
+        for b in (3, 12):
+            one = rh.postprocess(cls[b:b + 1].contiguous(), reg[b:b + 1].contiguous(), anchors, (size, size),
+                                 mode=mode)
+            assert len(one) == 1 and one[0]["scores"].numel() > 100
+            so, lo, bo = O.postprocess_image(cls[b].cpu().numpy(), reg[b].cpu().numpy(), anchors.cpu().numpy(),
+                                             size, size, mode=mode, boxes=boxes_all[b].cpu().numpy())
+            assert np.array_equal(one[0]["scores"].cpu().numpy(), so), (rep, b)
+            assert np.array_equal(one[0]["labels"].cpu().numpy(), lo), (rep, b)
+            assert np.array_equal(one[0]["boxes"].cpu().numpy(), bo), (rep, b)
+            for k in ("scores", "labels", "boxes"):
+                assert torch.equal(one[0][k], batch[b][k]), (rep, b, k)
+
+
 def test_nms_properties_large(rh):
     rng = np.random.default_rng(0)
     k = 12000

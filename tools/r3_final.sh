@@ -15,6 +15,8 @@ if [ "$1" = a ]; then
   tools/collect_profiles.sh r03 > $o/collect_r03.txt 2>&1 || { tail -5 $o/collect_r03.txt; exit 1; }
   echo "profiles collected"
 else
+  timeout -k 10 300 python bench.py > $o/r03_bench_line_default.json 2> $o/r03_bench_default.err || { tail -5 $o/r03_bench_default.err; exit 1; }
+  echo "default bench run done"
   timeout -k 10 400 tools/pmc_traffic.sh > $o/pmc_r03.txt 2>&1 || { tail -5 $o/pmc_r03.txt; exit 1; }
   echo "pmc done"
   timeout -k 10 900 tools/config_table.sh > $o/configs.txt 2> $o/configs.err || { tail -5 $o/configs.err; exit 1; }
