@@ -211,6 +211,37 @@ def test_captured_prefetch_buffers_outlive_eager_steps_of_other_shapes(rh):
     del junk
 
 
+def test_annotations_uploaded_on_a_side_stream(rh):
+    """A loader uploads the next batch's annotations on a stream of its own (pinned memory,
+    non_blocking) while the current step runs; ordered before the step that carries their
+    assignment by wait_stream, as the docstring of prefetch_assignment asks, the announced steps
+    give the plain results."""
+    size, c, m = 160, 20, 6
+    batches = [make_batch(40 + i, 2, size, c, m, [m, 3]) for i in range(4)]
+    anc = dev(batches[0][2])
+    plain = rh.FocalLoss()
+    want = [run_step(plain, dev(b[0]), dev(b[1]), anc, dev(b[3])) for b in batches]
+    loader = torch.cuda.Stream()
+    host = [torch.from_numpy(b[3]).pin_memory() for b in batches]
+    slots = [torch.empty_like(dev(batches[0][3])) for _ in range(2)]
+
+    def upload(i):
+        loader.wait_stream(torch.cuda.current_stream())      # the slot's previous reader is done
+        with torch.cuda.stream(loader):
+            slots[i % 2].copy_(host[i], non_blocking=True)
+
+    mod = rh.FocalLoss()
+    upload(0)
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            upload(i + 1)
+        torch.cuda.current_stream().wait_stream(loader)       # both uploads precede this step's launch
+        if i + 1 < len(batches):
+            mod.prefetch_assignment(anc, slots[(i + 1) % 2], c)
+        got = run_step(mod, dev(batches[i][0]), dev(batches[i][1]), anc, slots[i % 2])
+        assert same(got, want[i]), i
+
+
 def test_assignment_stage_on_its_own_stream(rh):
     """functional.focal_assign: the assignment stage issued apart (here on a second stream, ordered
     by events) into a workspace of its own; the remaining stages then give the plain call's bits."""
