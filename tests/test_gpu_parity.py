@@ -831,6 +831,52 @@ def test_nms_vs_oracle(rh, k):
     assert np.array_equal(keep2, O.nms(boxes, scores, 0.3))
 
 
+@pytest.mark.parametrize("thr", [0.5, 0.55, 0.75])
+def test_nms_pairs_on_the_threshold_with_centres_on_the_edges(rh, thr):
+    """From a threshold of one half on the pair search also requires each box's centre inside the
+    other box.  The cases where that rule is tightest: a box nested in a corner or along an edge of
+    another so that their IoU is the threshold give or take a few ulp -- the larger box's centre
+    then lies on the smaller one's edge -- and shifted copies whose IoU is the threshold.  Pairs
+    are placed apart from one another; which of them suppress is decided by the float32
+    division, exactly as the oracle (torchvision's arithmetic) decides it."""
+    rng = np.random.default_rng(int(thr * 100))
+    boxes, cell = [], 250.0
+    per_row = 40
+    n_pairs = 2000
+    for i in range(n_pairs):
+        ox, oy = (i % per_row) * cell, (i // per_row) * cell
+        w, h = rng.uniform(8, 100), rng.uniform(8, 100)
+        x, y = ox + rng.uniform(0, 100), oy + rng.uniform(0, 100)
+        f = thr * (1.0 + rng.choice([-3, -1, 0, 1, 3]) * 6e-8 * rng.integers(0, 3))
+        kind = i % 6
+        a = [x, y, x + w, y + h]
+        if kind == 0:        # nested, sharing the left edge: IoU = f
+            b = [x, y, x + w * f, y + h]
+        elif kind == 1:      # nested, sharing the right edge
+            b = [x + w * (1 - f), y, x + w, y + h]
+        elif kind == 2:      # nested, sharing the top edge
+            b = [x, y, x + w, y + h * f]
+        elif kind == 3:      # nested in a corner: sqrt(f) of each side
+            g = np.sqrt(f)
+            b = [x + w * (1 - g), y + h * (1 - g), x + w, y + h]
+        elif kind == 4:      # a copy shifted along x: IoU = (w - d) / (w + d)
+            d = w * (1 - f) / (1 + f)
+            b = [x + d, y, x + w + d, y + h]
+        else:                # a copy shifted along both axes (same IoU from both)
+            s = 1 - np.sqrt(2 * f / (1 + f))
+            b = [x + w * s, y + h * s, x + w + w * s, y + h + h * s]
+        boxes += [a, b]
+    boxes = np.asarray(boxes, np.float32)
+    scores = rng.permutation(len(boxes)).astype(np.float32) / len(boxes) * 0.9 + 0.05
+    order = rng.permutation(len(boxes))              # partners far apart in the list as well
+    boxes, scores = boxes[order], scores[order]
+    want = O.nms(boxes, scores, thr)
+    dropped = len(boxes) - len(want)
+    assert n_pairs * 0.2 < dropped < n_pairs * 0.8   # the cases do straddle the threshold
+    keep = rh.nms(dev(boxes), dev(scores), thr).cpu().numpy()
+    assert np.array_equal(keep, want)
+
+
 @pytest.mark.parametrize("kind", ["one_bin", "two_values", "below_the_bins", "logits", "wide"])
 def test_nms_score_distributions_of_the_rank_sort(rh, kind):
     """The rank sort buckets the list by the scores' upper bits and compares a key only inside its
