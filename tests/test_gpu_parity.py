@@ -157,6 +157,66 @@ def test_assign_ties_across_the_waves_of_the_split_form(rh):
     assert int(asg["argmax"][0, 4000]) == 5 and int(asg["label"][0, 4000]) == 1
 
 
+@pytest.mark.parametrize("m", [96, 400])
+def test_loss_assignment_cull_on_the_thresholds(rh, m):
+    """The loss wants packed codes only, so its assignment drops boxes that cannot reach the lower
+    IoU threshold with any anchor of a wave (area ratio, share of a side inside the wave's
+    bounding box).  Boxes built to sit ON the thresholds are where that is tightest: an anchor
+    nested in the box (IoU = area ratio), the box nested in an anchor, a box that shares an
+    anchor's full height and a threshold's share of its width, shifted copies -- each with IoU
+    0.4 or 0.5 give or take a few ulp.  The loss's view of every anchor (positive: a regression
+    gradient; ignored: no classification gradient; negative otherwise) must be the state that
+    rh_assign, which culls nothing of the kind, and the oracle give."""
+    rng = np.random.default_rng(900 + m)
+    size, c, bsz = 256, 6, 2
+    anc = O.anchors_for_image(size, size)
+    n = anc.shape[1]
+    ann = -np.ones((bsz, m, 5), np.float32)
+    for j in range(bsz):
+        rows = []
+        for i in range(m):
+            a = anc[0, rng.integers(0, n)].astype(np.float64)
+            w, h = a[2] - a[0], a[3] - a[1]
+            thr = (0.4, 0.5)[i % 2]
+            f = thr * (1.0 + rng.choice([-2, -1, 0, 1, 2]) * 6e-8 * rng.integers(0, 3))
+            kind = (i // 2) % 5
+            if kind == 0:      # anchor nested in the box, same height: IoU = w / W
+                b = [a[0], a[1], a[0] + w / f, a[3]]
+            elif kind == 1:    # box nested in the anchor along x
+                b = [a[0], a[1], a[0] + w * f, a[3]]
+            elif kind == 2:    # box nested in the anchor along y, anchored below
+                b = [a[0], a[3] - h * f, a[2], a[3]]
+            elif kind == 3:    # the anchor shifted along x
+                d = w * (1 - f) / (1 + f)
+                b = [a[0] + d, a[1], a[2] + d, a[3]]
+            else:              # anchor nested in a corner of the box
+                g = np.sqrt(f)
+                b = [a[2] - w / g, a[3] - h / g, a[2], a[3]]
+            rows.append(b + [float(rng.integers(0, c))])
+        ann[j] = np.asarray(rows, np.float32)
+        if j == 1:
+            ann[j, rng.random(m) < 0.3] = -1          # padding rows among them
+    cls = rng.uniform(0.01, 0.6, (bsz, n, c)).astype(np.float32)
+    reg = rng.normal(0, 1, (bsz, n, 4)).astype(np.float32)
+    asg = rh.functional.assign(dev(anc), dev(ann), c)
+    out = rh.functional.focal_loss_fwd_bwd(dev(cls), dev(reg), dev(anc), dev(ann))
+    d_cls, d_reg = out["d_classifications"].cpu().numpy(), out["d_regressions"].cpu().numpy()
+    on_threshold = 0
+    for j in range(bsz):
+        ref = O.assign(anc[0], ann[j])
+        state = asg["state"][j].cpu().numpy()
+        assert np.array_equal(state, ref["state"]), j
+        assert int(out["num_pos"][j]) == ref["num_pos"] == int((state == 2).sum()), j
+        assert np.array_equal((d_cls[j] == 0).all(axis=1), state == 1), j        # ignored rows
+        assert np.array_equal((d_reg[j] != 0).any(axis=1), state == 2), j        # positive rows
+        iou = ref["iou_max"]
+        on_threshold += int((np.abs(iou - 0.4) < 1e-6).sum() + (np.abs(iou - 0.5) < 1e-6).sum())
+    assert on_threshold > m // 2          # the construction does put anchors on the thresholds
+    want = O.focal_loss_fwd_bwd(cls, reg, anc, ann)
+    assert np.allclose(out["losses"].cpu().numpy(),
+                       [want["classification_loss"][0], want["regression_loss"][0]], rtol=RTOL, atol=0)
+
+
 def make_batch(seed, bsz, size, c, m, valid):
     rng = np.random.default_rng(seed)
     anc = O.anchors_for_image(size, size)
