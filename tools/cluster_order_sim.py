@@ -69,3 +69,41 @@ for j in range(2):
     mort2=part1by1(cxq)|(part1by1(cyq)<<1)
     key=np.lexsort((mort2,cls_))
     print("   area class + morton of centre:",survivors(key,boxes))
+
+
+def survivors_sub(order, boxes, sub):
+    """As survivors(), with cluster A cut into `sub` runs of consecutive entries: a box of B is kept only if
+    it passes the lane test against at least one run's bounding box / area range / centres."""
+    b = boxes[order]; K = len(b); nc = (K + 63) // 64
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]); cx = (b[:, 0] + b[:, 2]) / 2; cy = (b[:, 1] + b[:, 3]) / 2
+    cl = [slice(i * 64, min(K, (i + 1) * 64)) for i in range(nc)]
+    bb = np.array([[b[s, 0].min(), b[s, 1].min(), b[s, 2].max(), b[s, 3].max()] for s in cl])
+    ar = np.array([[area[s].min(), area[s].max()] for s in cl])
+    cb = np.array([[cx[s].min(), cy[s].min(), cx[s].max(), cy[s].max()] for s in cl])
+    f = 0.5 * 0.9999
+    step = 64 // sub
+    surv = 0
+    for A in range(nc):
+        runs = [slice(A * 64 + q * step, min(K, A * 64 + (q + 1) * step)) for q in range(sub)]
+        runs = [r for r in runs if r.start < K]
+        rb = [(b[r, 0].min(), b[r, 1].min(), b[r, 2].max(), b[r, 3].max(), area[r].min(), area[r].max()) for r in runs]
+        for B in range(A, nc):
+            if bb[B, 2] <= bb[A, 0] or bb[B, 0] >= bb[A, 2] or bb[B, 3] <= bb[A, 1] or bb[B, 1] >= bb[A, 3]: continue
+            if ar[B, 0] * f > ar[A, 1] or ar[B, 1] < ar[A, 0] * f: continue
+            if cb[B, 2] < bb[A, 0] or cb[B, 0] > bb[A, 2] or cb[B, 3] < bb[A, 1] or cb[B, 1] > bb[A, 3]: continue
+            if cb[A, 2] < bb[B, 0] or cb[A, 0] > bb[B, 2] or cb[A, 3] < bb[B, 1] or cb[A, 1] > bb[B, 3]: continue
+            s = cl[B]
+            ok = np.zeros(s.stop - s.start, bool)
+            for (x1, y1, x2, y2, amin, amax) in rb:
+                o = (cx[s] >= x1) & (cx[s] <= x2) & (cy[s] >= y1) & (cy[s] <= y2)
+                o &= (area[s] * f <= amax) & (area[s] >= amin * f)
+                ok |= o
+            surv += int(ok.sum())
+    return surv
+
+
+for j in range(2):
+    sc = icls[j].max(1); cand = np.nonzero(sc > 0.05)[0]
+    boxes = decode(anc[cand], ireg[j][cand])
+    base = np.arange(len(cand))
+    print("image", j, "runs of A:", {sub: survivors_sub(base, boxes, sub) for sub in (1, 2, 4, 8, 16)})
