@@ -1855,6 +1855,207 @@ __global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restric
 }
 
 // ---------------------------------------------------------------------------
+// Pair search by a hash of the box centres (thresholds from one half on, boxes inside a known
+// image): the same predecessor words as nms_pairs_kernel leaves, found another way.
+//
+// Two boxes with IoU > thresh >= 1/2 contain each other's centre and differ in area by less than
+// a factor two (the intersection is at most the smaller area, the union at least the larger one;
+// the float32 quotient stays within a few ulp of that, the bounds below carry a margin of 1e-5).
+// So the box with the SMALLER area (equal areas: the lower rank) owns the pair, and all it has to
+// look at are boxes of its own area class (a class is a binade of the area) or the next one,
+// whose centres lie inside it.  Boxes are binned by (area class, cell of the centre), cells of
+// class c being about as large as the boxes of class c, so a box covers a handful of cells per
+// class and a cell holds a handful of boxes -- about 30 candidates per box at the benchmark's
+// density instead of the ~170 that survive the cluster tests of nms_pairs_kernel.
+//
+// Every workgroup of an image builds the image's table in LDS (boxes, a counting sort of the
+// box indices by cell: LDS atomics for the counts and the places inside a cell, whose order
+// does not matter -- the result is a set of bits) and then handles its share of the owners,
+// four threads per owner, which share the entries of each cell.  Candidates that own nothing, lie
+// outside the area window or have their centre outside the owner's box (with the slack of
+// nms_pairs_kernel's centre rule) are dropped; the rest get torchvision's float32 division.
+// A box without area (or with a NaN coordinate) is in no cell and owns nothing: its IoU with
+// anything is 0 or NaN, never above a threshold.
+// ---------------------------------------------------------------------------
+constexpr int kHashThreads = 512;
+constexpr int kHashMaxClasses = 20;
+#ifndef RH_HASH_SHARE
+#define RH_HASH_SHARE 4
+#endif
+constexpr int kHashShare = RH_HASH_SHARE;           // threads per owner
+struct HashGeom {
+  int classes;                    // area classes: class c holds areas in [2^(e0 + c), 2^(e0 + c + 1)),
+  int e0;                         // the first one everything below, the last one everything above
+  int cells;                      // all classes together
+  float inv_g[kHashMaxClasses];   // 1 / cell size
+  int nx[kHashMaxClasses], ny[kHashMaxClasses], base[kHashMaxClasses];
+};
+
+__host__ __device__ inline size_t hash_lds_bytes(int box_cap, int cells) {
+  return (size_t)box_cap * sizeof(float4) + ((size_t)cells + 1) * sizeof(unsigned) +
+         (size_t)box_cap * 3 * sizeof(unsigned short);
+}
+
+__device__ __forceinline__ int hash_class(const float area, const int e0, const int classes) {
+  const int e = (int)((__float_as_uint(area) >> 23) & 255u) - 127;      // floor(log2(area))
+  return min(max(e - e0, 0), classes - 1);
+}
+
+template <bool kPerClass>
+__global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
+    const float4* __restrict__ sbox, const int* __restrict__ slabel, const int* __restrict__ keff,
+    u64* __restrict__ mask, u64* __restrict__ nz, int box_stride, int wstride, int nzw,
+    float thresh, const HashGeom geo) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_hbox[];              // [box_stride]
+  unsigned* s_off = reinterpret_cast<unsigned*>(s_hbox + box_stride);          // [cells + 1]
+  unsigned short* s_cell = reinterpret_cast<unsigned short*>(s_off + geo.cells + 1);   // [box_stride]
+  unsigned short* s_pos = s_cell + box_stride;                                 // [box_stride]
+  unsigned short* s_item = s_pos + box_stride;                                 // [box_stride]
+  __shared__ float s_inv[kHashMaxClasses];
+  __shared__ int s_nx[kHashMaxClasses], s_ny[kHashMaxClasses], s_base[kHashMaxClasses];
+  __shared__ unsigned s_wtot[kHashThreads / 64];
+  const int j = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = min(keff[j], box_stride);
+  if (K < 2) return;                                   // block-uniform
+  const float4* bj = sbox + (size_t)j * box_stride;
+  const int cells = geo.cells;
+  for (int i = tid; i <= cells; i += kHashThreads) s_off[i] = 0u;
+  if (tid < kHashMaxClasses) {
+    s_inv[tid] = geo.inv_g[tid];
+    s_nx[tid] = geo.nx[tid];
+    s_ny[tid] = geo.ny[tid];
+    s_base[tid] = geo.base[tid];
+  }
+  // the boxes are requested before the barrier that publishes the zeroed counts
+  constexpr int kPer = 8;                              // boxes per thread at the 4096-box limit
+  float4 mine[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) mine[u] = bj[min(tid + u * kHashThreads, box_stride - 1)];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int p = tid + u * kHashThreads;
+    if (p < K) {
+      const float4 b = mine[u];
+      s_hbox[p] = b;
+      const float area = (b.z - b.x) * (b.w - b.y);
+      unsigned short cell = 0xFFFFu, pos = 0;
+      if (area > 0.0f && area < __builtin_inff()) {    // (false for NaN)
+        const int c = hash_class(area, geo.e0, geo.classes);
+        const float cx = (b.x + b.z) * 0.5f, cy = (b.y + b.w) * 0.5f;
+        const int ix = min(max((int)(cx * s_inv[c]), 0), s_nx[c] - 1);
+        const int iy = min(max((int)(cy * s_inv[c]), 0), s_ny[c] - 1);
+        const int at = s_base[c] + iy * s_nx[c] + ix;
+        cell = (unsigned short)at;
+        pos = (unsigned short)atomicAdd(&s_off[at], 1u);
+      }
+      s_cell[p] = cell;
+      s_pos[p] = pos;
+    }
+  }
+  __syncthreads();
+  // exclusive prefix over the cells' counts, in place: a run of cells per thread, the runs'
+  // totals by wave scans
+  {
+    const int run = (cells + kHashThreads - 1) / kHashThreads;
+    const int lo = min(tid * run, cells), hi = min(lo + run, cells);
+    unsigned tot = 0;
+    for (int i = lo; i < hi; ++i) tot += s_off[i];
+    unsigned incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    unsigned before = incl - tot;
+    for (int w = 0; w < wave; ++w) before += s_wtot[w];
+    for (int i = lo; i < hi; ++i) {
+      const unsigned c = s_off[i];
+      s_off[i] = before;
+      before += c;
+    }
+    if (tid == kHashThreads - 1) s_off[cells] = before;      // the last run's end: all boxes in cells
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int p = tid + u * kHashThreads;
+    if (p < K && s_cell[p] != 0xFFFFu) s_item[s_off[s_cell[p]] + s_pos[p]] = (unsigned short)p;
+  }
+  __syncthreads();
+
+  // ---- the owners of this workgroup: ranks g, g + G, ..; kHashShare threads each
+  const int G = gridDim.x, g = blockIdx.x;
+  const int sub = tid & (kHashShare - 1);
+  u64* mj = mask + (size_t)j * box_stride * wstride;
+  u64* nj = nz + (size_t)j * box_stride * nzw;
+  const int* lj = kPerClass ? slabel + (size_t)j * box_stride : nullptr;
+  for (int i = tid / kHashShare;; i += kHashThreads / kHashShare) {
+    const int p = g + i * G;
+    if (__ballot(p < K) == 0ull) break;
+    if (p >= K || s_cell[p] == 0xFFFFu) continue;
+    const float4 a = s_hbox[p];
+    const float wa = a.z - a.x, ha = a.w - a.y;
+    const float area = wa * ha;
+    const float a_max = area * 2.00002f;
+    // slack of the centre test: a thousandth of the box's larger side or of its largest
+    // coordinate (whose rounding the midpoints carry)
+    const float slack = 1e-3f * fmaxf(fmaxf(wa, ha), fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)),
+                                                          fmaxf(fabsf(a.z), fabsf(a.w))));
+    const float x_lo = a.x - slack, x_hi = a.z + slack, y_lo = a.y - slack, y_hi = a.w + slack;
+    const int c_lo = hash_class(area, geo.e0, geo.classes), c_hi = hash_class(a_max, geo.e0, geo.classes);
+    const int my_lab = kPerClass ? lj[p] : 0;
+    // One loop over the runs of entries (a run: the cells of one row of one class that the box
+    // reaches), a step of it either takes an entry or moves on to the next run: the lanes of a
+    // wave then need as many steps as the busiest lane has entries and runs, not the sum over the
+    // runs of the busiest lane in each.
+    int c = c_lo - 1, iy = 0, iy1 = -1, ix0 = 0, ix1 = 0, nx = 0, base = 0;
+    unsigned e = 0, e_end = 0;
+    for (;;) {
+      if (e < e_end) {
+        const int q = s_item[e];
+        e += kHashShare;
+        const float4 b = s_hbox[q];
+        const float area_b = (b.z - b.x) * (b.w - b.y);
+        // the smaller area owns the pair (equal areas: the lower rank)
+        const bool owned = area_b > area || (area_b == area && q > p);
+        const float cx = (b.x + b.z) * 0.5f, cy = (b.y + b.w) * 0.5f;
+        if (!owned || area_b > a_max || cx < x_lo || cx > x_hi || cy < y_lo || cy > y_hi) continue;
+        if (kPerClass && lj[q] != my_lab) continue;
+        const float w = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+        const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+        const float inter = w * h;
+        if (nms_hit_exact(inter, (area + area_b) - inter, thresh)) {
+          const int first = min(p, q), later = max(p, q);
+          const int word = first >> 6;
+          atomicOr(&mj[(size_t)word * box_stride + later], 1ull << (first & 63));
+          atomicOr(&nj[(size_t)later * nzw + (word >> 6)], 1ull << (word & 63));
+        }
+        continue;
+      }
+      if (++iy > iy1) {                 // next class
+        if (++c > c_hi) break;
+        const float inv = s_inv[c];
+        nx = s_nx[c];
+        base = s_base[c];
+        ix0 = min(max((int)(x_lo * inv), 0), nx - 1);
+        ix1 = min(max((int)(x_hi * inv), 0), nx - 1);
+        iy = min(max((int)(y_lo * inv), 0), s_ny[c] - 1);
+        iy1 = min(max((int)(y_hi * inv), 0), s_ny[c] - 1);
+      }
+      // the cells of a row are consecutive: one run of entries from the first cell's start to
+      // the last cell's end
+      const int row = base + iy * nx;
+      e = s_off[row + ix0] + sub;
+      e_end = s_off[row + ix1 + 1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Resolve kernel: which boxes survive the greedy pass, from the sparse predecessor words.
 // Box i is dropped iff a KEPT box that precedes it overlaps it.  One workgroup per image keeps two
 // bitmaps over the boxes in LDS, `lo` (surely kept) and `hi` (possibly kept), starting from
@@ -2371,16 +2572,58 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
   return RH_OK;
 }
 
+#ifndef RH_PAIR_HASH
+#define RH_PAIR_HASH 1
+#endif
+// Geometry of the centre hash for boxes inside [0, width] x [0, height]; false when the hash
+// form does not apply (the cluster form then runs).
+static bool hash_geometry(const NmsPlan& p, float thresh, float width, float height, HashGeom* out) {
+  if (!RH_PAIR_HASH || !(thresh >= 0.5f) || !(thresh < 1e30f) || p.box_cap > 8 * kHashThreads) return false;
+  if (!(width >= 1.0f) || !(height >= 1.0f) || !(width <= 16384.0f) || !(height <= 16384.0f)) return false;
+  HashGeom g{};
+  g.e0 = 8;
+  int top = 0;
+  while (top < 40 && std::ldexp(1.0f, top + 1) <= width * height) ++top;       // floor(log2(W * H))
+  g.classes = std::min(std::max(top - g.e0 + 1, 1), kHashMaxClasses);
+  int cells = 0;
+  for (int c = 0; c < g.classes; ++c) {
+    const float size = std::max(16.0f, std::sqrt(std::ldexp(1.0f, g.e0 + c)));
+    g.inv_g[c] = 1.0f / size;
+    g.nx[c] = (int)(width * g.inv_g[c]) + 1;
+    g.ny[c] = (int)(height * g.inv_g[c]) + 1;
+    g.base[c] = cells;
+    cells += g.nx[c] * g.ny[c];
+  }
+  g.cells = cells;
+  if (cells >= 65535 || hash_lds_bytes(p.box_cap, cells) > 150 * 1024) return false;
+  *out = g;
+  return true;
+}
+
+// width, height: the image the boxes were clipped to (0: unknown)
 static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, int per_class,
-                      SweepOut out, hipStream_t s) {
+                      SweepOut out, hipStream_t s, float width = 0.0f, float height = 0.0f) {
   if (int e = check_plan(p)) return e;
   const int* keff = w.counters + 2 * p.batch;
-  if (thresh > 0.0f && thresh < 1e30f) {
-    if (!p.ranked) {
-      hipLaunchKernelGGL(cluster_prepare_kernel, dim3(p.clusters, p.batch), dim3(64), 0, s, w.sbox,
-                         w.slabel, keff, w.csum, w.cinfo, w.mask, p.box_cap, p.wstride, p.clusters);
-      RH_CHECK_LAUNCH("cluster_prepare_kernel");
-    }
+  if (thresh > 0.0f && thresh < 1e30f && !p.ranked) {
+    // (sort paths other than the rank sort: this kernel zeroes the predecessor words -- both
+    // pair kernels OR into them -- and leaves the cluster summaries of the cluster form)
+    hipLaunchKernelGGL(cluster_prepare_kernel, dim3(p.clusters, p.batch), dim3(64), 0, s, w.sbox,
+                       w.slabel, keff, w.csum, w.cinfo, w.mask, p.box_cap, p.wstride, p.clusters);
+    RH_CHECK_LAUNCH("cluster_prepare_kernel");
+  }
+  HashGeom geo;
+  if (hash_geometry(p, thresh, width, height, &geo)) {
+    int cus = 0;
+    if (int e = compute_units(&cus)) return e;
+    const int per_image = std::max(1, std::min(16, cus / p.batch));
+    const size_t lds = hash_lds_bytes(p.box_cap, geo.cells);
+    auto kern = per_class ? nms_pairs_hash_kernel<true> : nms_pairs_hash_kernel<false>;
+    if (int e = allow_lds(kern, lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(per_image, p.batch), dim3(kHashThreads), lds, s, w.sbox, w.slabel, keff,
+                       w.mask, w.nz, p.box_cap, p.wstride, p.nzw, thresh, geo);
+    RH_CHECK_LAUNCH("nms_pairs_hash_kernel");
+  } else if (thresh > 0.0f && thresh < 1e30f) {
     // `slices` blocks (kPairThreads / 64 waves each) share the cluster pairs of one cluster (the bench workload
     // above with 1 / 2 / 4 / 8 slices: 96.0 / 93.3 / 95.9 / 99.7 us per call)
     int slices = 1;                                   // a power of two (the kernel masks with it)
@@ -2685,7 +2928,7 @@ int rh_postprocess(const float* classifications, const float* regressions, const
     out.cand_out = cand_count;
     out.ovf_out = overflow;
     out.batch = batch;
-    if (int e = launch_nms(p, w, q->iou_thresh, q->per_class, out, s)) return e;
+    if (int e = launch_nms(p, w, q->iou_thresh, q->per_class, out, s, q->width, q->height)) return e;
   }
   return RH_OK;
 }
@@ -2800,7 +3043,7 @@ int rh_postprocess_levels(const float* const* cls_levels, const float* const* re
     out.cand_out = cand_count;
     out.ovf_out = overflow;
     out.batch = batch;
-    if (int e = launch_nms(p, w, q->iou_thresh, q->per_class, out, s)) return e;
+    if (int e = launch_nms(p, w, q->iou_thresh, q->per_class, out, s, q->width, q->height)) return e;
   }
   return RH_OK;
 }

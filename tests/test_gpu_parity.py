@@ -1190,6 +1190,96 @@ def test_postprocess_per_class_topk_maxdet(rh):
     check_post(rh, cls, reg, anc, 192, pre_nms_topk=1000, max_det=50)
 
 
+def boxes_as_head_outputs(boxes, scores, labels, c):
+    """Inputs whose decoded boxes are `boxes` (zero deltas on anchors equal to them) with one
+    score per row at its label's column."""
+    n = len(boxes)
+    cls = np.zeros((1, n, c), np.float32)
+    cls[0, np.arange(n), labels] = scores
+    return cls, np.zeros((1, n, 4), np.float32), np.asarray(boxes, np.float32)[None]
+
+
+def check_post_hw(rh, cls, reg, anc, hw, **kw):
+    h, w = hw
+    res = rh.postprocess(dev(cls), dev(reg), dev(anc), hw, **kw)[0]
+    dboxes = rh.ClipBoxes()(rh.BBoxTransform()(dev(anc), dev(reg)),
+                            torch.empty(1, 3, h, w, device="cuda")).cpu().numpy()
+    s, l, bx = O.postprocess_image(cls[0], reg[0], anc, h, w, boxes=dboxes[0], **kw)
+    assert np.array_equal(res["labels"].cpu().numpy(), l)
+    assert np.array_equal(res["scores"].cpu().numpy(), s)
+    assert np.array_equal(res["boxes"].cpu().numpy(), bx)
+    return len(s)
+
+
+@pytest.mark.parametrize("hw", [(1000, 1300), (3000, 20000)])
+@pytest.mark.parametrize("case", ["threshold", "one_spot", "shapes"])
+def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
+    """Box sets that strain the pair search of the fused call, which for thresholds from one half
+    on and images of moderate size bins the boxes by area and centre and otherwise (the wide
+    image here) compares clusters of the ranked list: pairs whose IoU is the threshold give or take
+    an ulp with a centre on the partner's edge; thousands of boxes around one spot (one bin holds
+    them all); thin, tiny, empty and image-sized boxes."""
+    h, w = hw
+    rng = np.random.default_rng(len(case) + h)
+    c = 4
+    if case == "threshold":
+        thr = 0.5
+        boxes = []
+        for i in range(1700):
+            bw, bh = rng.uniform(8, 100), rng.uniform(8, 100)
+            x, y = rng.uniform(0, min(w, 1300) - 110), rng.uniform(0, h - 110)
+            f = thr * (1.0 + rng.choice([-3, -1, 0, 1, 3]) * 6e-8 * rng.integers(0, 3))
+            a = [x, y, x + bw, y + bh]
+            kind = i % 4
+            if kind == 0:        # nested, sharing an edge: the larger box's centre on the smaller's edge
+                b = [x, y, x + bw * f, y + bh]
+            elif kind == 1:      # nested in a corner
+                g = np.sqrt(f)
+                b = [x + bw * (1 - g), y + bh * (1 - g), x + bw, y + bh]
+            elif kind == 2:      # a shifted copy: equal areas
+                d = bw * (1 - f) / (1 + f)
+                b = [x + d, y, x + bw + d, y + bh]
+            else:                # twice the area, the smaller box inside: IoU = 1/2 from the area bound
+                b = [x, y, x + bw, y + 2 * bh * (1.0 + rng.choice([-1, 0, 1]) * 1e-7)]
+            boxes += [a, b]
+        boxes = np.asarray(boxes, np.float32)
+    elif case == "one_spot":
+        k = 3500
+        ctr = np.array([w * 0.37, h * 0.61]) + rng.normal(0, 3, (k, 2))
+        wh = rng.uniform(20, 28, (k, 2))
+        boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+        boxes[::50] = boxes[1::50]                       # exact copies
+    else:
+        k = 3000
+        ctr = rng.uniform(0, 1, (k, 2)) * [min(w, 1300), h]
+        wh = np.empty((k, 2))
+        kinds = rng.integers(0, 6, k)
+        wh[kinds == 0] = rng.uniform(0.05, 0.9, ((kinds == 0).sum(), 2))            # under a pixel
+        wh[kinds == 1] = np.stack([rng.uniform(1, 3, (kinds == 1).sum()),
+                                   rng.uniform(300, 900, (kinds == 1).sum())], 1)   # thin, tall
+        wh[kinds == 2] = np.stack([rng.uniform(300, 1200, (kinds == 2).sum()),
+                                   rng.uniform(1, 3, (kinds == 2).sum())], 1)       # thin, wide
+        wh[kinds == 3] = rng.uniform(700, 2600, ((kinds == 3).sum(), 2))            # clipped to the image
+        wh[kinds == 4] = rng.uniform(10, 60, ((kinds == 4).sum(), 2))
+        wh[kinds == 5] = 0.0                                                        # empty
+        ctr[kinds == 1, 0] = np.round(ctr[kinds == 1, 0] / 40) * 40                 # so that they do overlap
+        ctr[kinds == 2, 1] = np.round(ctr[kinds == 2, 1] / 40) * 40
+        boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    n = len(boxes)
+    order = rng.permutation(n)
+    boxes = boxes[order]
+    scores = (rng.permutation(n).astype(np.float32) / n * 0.9 + 0.06).astype(np.float32)
+    labels = rng.integers(0, c, n)
+    cls, reg, anc = boxes_as_head_outputs(boxes, scores, labels, c)
+    kept = check_post_hw(rh, cls, reg, anc, hw)
+    assert 0 < kept < n                                   # some suppression did happen
+    kept_pc = check_post_hw(rh, cls, reg, anc, hw, mode="per_class")
+    assert kept <= kept_pc < n
+    check_post_hw(rh, cls, reg, anc, hw, iou_thresh=0.75)
+    check_post_hw(rh, cls, reg, anc, hw, iou_thresh=0.45)  # below one half: the cluster form
+    check_post_hw(rh, cls, reg, anc, hw, pre_nms_topk=700, mode="per_class")
+
+
 def test_postprocess_topk_preselection(rh):
     """pre_nms_topk at most half the candidate room goes through the histogram pre-selection:
     heavy score ties (the bin that straddles the cut holds hundreds of equal scores, resolved by
