@@ -1865,24 +1865,44 @@ __global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restric
 // look at are boxes of its own area class (a class is a binade of the area) or the next one,
 // whose centres lie inside it.  Boxes are binned by (area class, cell of the centre), cells of
 // class c being about as large as the boxes of class c, so a box covers a handful of cells per
-// class and a cell holds a handful of boxes -- about 30 candidates per box at the benchmark's
+// class and a cell holds a handful of boxes -- about 18 candidates per box at the benchmark's
 // density instead of the ~170 that survive the cluster tests of nms_pairs_kernel.
 //
-// Every workgroup of an image builds the image's table in LDS (boxes, a counting sort of the
-// box indices by cell: LDS atomics for the counts and the places inside a cell, whose order
-// does not matter -- the result is a set of bits) and then handles its share of the owners,
-// four threads per owner, which share the entries of each cell.  Candidates that own nothing, lie
-// outside the area window or have their centre outside the owner's box (with the slack of
-// nms_pairs_kernel's centre rule) are dropped; the rest get torchvision's float32 division.
+// Every workgroup of an image builds the image's table in LDS: a counting sort of the boxes by
+// cell (LDS atomics for the counts and for the places inside a cell -- their order is left to
+// chance, the result is a set of bits), which leaves the boxes themselves in cell order, their
+// ranks beside them, and for every rank the place of its box.  Then the workgroup handles its
+// share of the owners (ranks g, g + G, ..: a split by place in the table would differ from
+// workgroup to workgroup), four threads per owner.  The cells of one row of one class that an
+// owner reaches are consecutive, so their entries form one run; the owner's runs (typically
+// four, two or three rows in each of two classes) are walked as a single sequence of which the
+// four threads take every fourth entry.  Candidates that own nothing, lie outside the area
+// window or have their centre outside the owner's box (with the slack of nms_pairs_kernel's
+// centre rule) are dropped; the rest get torchvision's float32 division.
 // A box without area (or with a NaN coordinate) is in no cell and owns nothing: its IoU with
 // anything is 0 or NaN, never above a threshold.
+// 608 px, 8 images of ~2 000 boxes: 11.6 us (5.3 of them launch + table) against 15.1 us for
+// nms_pairs_kernel; the walk with one loop per run 13.1, with the boxes looked up through their
+// ranks 13.6, with the runs dealt out to the four threads 13.6, two / eight threads per owner
+// 13.8 / 12.4, 1024-thread workgroups 13.8.
 // ---------------------------------------------------------------------------
-constexpr int kHashThreads = 512;
+#ifndef RH_HASH_THREADS
+#define RH_HASH_THREADS 512
+#endif
+constexpr int kHashThreads = RH_HASH_THREADS;
+constexpr int kHashMaxBoxes = 4096;
 constexpr int kHashMaxClasses = 20;
 #ifndef RH_HASH_SHARE
 #define RH_HASH_SHARE 4
 #endif
 constexpr int kHashShare = RH_HASH_SHARE;           // threads per owner
+#ifndef RH_HASH_UNROLL
+#define RH_HASH_UNROLL 1
+#endif
+#ifndef RH_HASH_RUNS
+#define RH_HASH_RUNS 8
+#endif
+constexpr int kHashRuns = RH_HASH_RUNS;             // runs of entries taken together
 struct HashGeom {
   int classes;                    // area classes: class c holds areas in [2^(e0 + c), 2^(e0 + c + 1)),
   int e0;                         // the first one everything below, the last one everything above
@@ -1893,7 +1913,7 @@ struct HashGeom {
 
 __host__ __device__ inline size_t hash_lds_bytes(int box_cap, int cells) {
   return (size_t)box_cap * sizeof(float4) + ((size_t)cells + 1) * sizeof(unsigned) +
-         (size_t)box_cap * 3 * sizeof(unsigned short);
+         (size_t)box_cap * 2 * sizeof(unsigned short);
 }
 
 __device__ __forceinline__ int hash_class(const float area, const int e0, const int classes) {
@@ -1906,19 +1926,24 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
     const float4* __restrict__ sbox, const int* __restrict__ slabel, const int* __restrict__ keff,
     u64* __restrict__ mask, u64* __restrict__ nz, int box_stride, int wstride, int nzw,
     float thresh, const HashGeom geo) {
-  extern __shared__ __attribute__((aligned(16))) float4 s_hbox[];              // [box_stride]
-  unsigned* s_off = reinterpret_cast<unsigned*>(s_hbox + box_stride);          // [cells + 1]
-  unsigned short* s_cell = reinterpret_cast<unsigned short*>(s_off + geo.cells + 1);   // [box_stride]
-  unsigned short* s_pos = s_cell + box_stride;                                 // [box_stride]
-  unsigned short* s_item = s_pos + box_stride;                                 // [box_stride]
+  // the table: the boxes in cell order, where each cell's boxes start, the boxes' ranks, and
+  // where the box of a rank is
+  extern __shared__ __attribute__((aligned(16))) float4 s_cbox[];              // [box_stride]
+  unsigned* s_off = reinterpret_cast<unsigned*>(s_cbox + box_stride);          // [cells + 1]
+  unsigned short* s_rank = reinterpret_cast<unsigned short*>(s_off + geo.cells + 1);   // [box_stride]
+  unsigned short* s_where = s_rank + box_stride;                               // [box_stride], 0xFFFF: nowhere
   __shared__ float s_inv[kHashMaxClasses];
   __shared__ int s_nx[kHashMaxClasses], s_ny[kHashMaxClasses], s_base[kHashMaxClasses];
   __shared__ unsigned s_wtot[kHashThreads / 64];
   const int j = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = min(keff[j], box_stride);
-  if (K < 2) return;                                   // block-uniform
   const float4* bj = sbox + (size_t)j * box_stride;
+  // the boxes are requested first of all (rows past the list's end are read and not used)
+  constexpr int kPer = kHashMaxBoxes / kHashThreads;
+  float4 mine[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) mine[u] = bj[min(tid + u * kHashThreads, box_stride - 1)];
+  const int K = min(keff[j], box_stride);
   const int cells = geo.cells;
   for (int i = tid; i <= cells; i += kHashThreads) s_off[i] = 0u;
   if (tid < kHashMaxClasses) {
@@ -1927,31 +1952,24 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
     s_ny[tid] = geo.ny[tid];
     s_base[tid] = geo.base[tid];
   }
-  // the boxes are requested before the barrier that publishes the zeroed counts
-  constexpr int kPer = 8;                              // boxes per thread at the 4096-box limit
-  float4 mine[kPer];
-#pragma unroll
-  for (int u = 0; u < kPer; ++u) mine[u] = bj[min(tid + u * kHashThreads, box_stride - 1)];
   __syncthreads();
+  unsigned cell[kPer], pos[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int p = tid + u * kHashThreads;
+    cell[u] = 0xFFFFu;
+    pos[u] = 0u;
     if (p < K) {
       const float4 b = mine[u];
-      s_hbox[p] = b;
       const float area = (b.z - b.x) * (b.w - b.y);
-      unsigned short cell = 0xFFFFu, pos = 0;
       if (area > 0.0f && area < __builtin_inff()) {    // (false for NaN)
         const int c = hash_class(area, geo.e0, geo.classes);
         const float cx = (b.x + b.z) * 0.5f, cy = (b.y + b.w) * 0.5f;
         const int ix = min(max((int)(cx * s_inv[c]), 0), s_nx[c] - 1);
         const int iy = min(max((int)(cy * s_inv[c]), 0), s_ny[c] - 1);
-        const int at = s_base[c] + iy * s_nx[c] + ix;
-        cell = (unsigned short)at;
-        pos = (unsigned short)atomicAdd(&s_off[at], 1u);
+        cell[u] = (unsigned)(s_base[c] + iy * s_nx[c] + ix);
+        pos[u] = atomicAdd(&s_off[cell[u]], 1u);
       }
-      s_cell[p] = cell;
-      s_pos[p] = pos;
     }
   }
   __syncthreads();
@@ -1983,21 +2001,30 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int p = tid + u * kHashThreads;
-    if (p < K && s_cell[p] != 0xFFFFu) s_item[s_off[s_cell[p]] + s_pos[p]] = (unsigned short)p;
+    unsigned at = 0xFFFFu;
+    if (cell[u] != 0xFFFFu) {
+      at = s_off[cell[u]] + pos[u];
+      s_cbox[at] = mine[u];
+      s_rank[at] = (unsigned short)p;
+    }
+    if (p < box_stride) s_where[p] = (unsigned short)at;
   }
   __syncthreads();
 
-  // ---- the owners of this workgroup: ranks g, g + G, ..; kHashShare threads each
+  // ---- the owners of this workgroup: ranks g, g + G, .. (by rank and not by place in the table:
+  // the order inside a cell differs from workgroup to workgroup), kHashShare threads each
   const int G = gridDim.x, g = blockIdx.x;
-  const int sub = tid & (kHashShare - 1);
+  const unsigned sub = tid & (kHashShare - 1);
   u64* mj = mask + (size_t)j * box_stride * wstride;
   u64* nj = nz + (size_t)j * box_stride * nzw;
   const int* lj = kPerClass ? slabel + (size_t)j * box_stride : nullptr;
   for (int i = tid / kHashShare;; i += kHashThreads / kHashShare) {
     const int p = g + i * G;
     if (__ballot(p < K) == 0ull) break;
-    if (p >= K || s_cell[p] == 0xFFFFu) continue;
-    const float4 a = s_hbox[p];
+    if (p >= K) continue;
+    const unsigned own = s_where[p];
+    if (own == 0xFFFFu) continue;
+    const float4 a = s_cbox[own];
     const float wa = a.z - a.x, ha = a.w - a.y;
     const float area = wa * ha;
     const float a_max = area * 2.00002f;
@@ -2006,51 +2033,87 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
     const float slack = 1e-3f * fmaxf(fmaxf(wa, ha), fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)),
                                                           fmaxf(fabsf(a.z), fabsf(a.w))));
     const float x_lo = a.x - slack, x_hi = a.z + slack, y_lo = a.y - slack, y_hi = a.w + slack;
-    const int c_lo = hash_class(area, geo.e0, geo.classes), c_hi = hash_class(a_max, geo.e0, geo.classes);
+    // The owner's class and the next one (twice the area: the next binade).  A box of the class
+    // after that has at least 2^(k+2) of area against less than 2^(k+1) here, and the float32
+    // quotient of an intersection below 2^(k+1) by a union of 2^(k+2) (1 - 2^-24) or more is at
+    // most one half -- however close to 2^(k+1) the owner's area is.
+    const int c_lo = hash_class(area, geo.e0, geo.classes), c_hi = hash_class(area * 2.0f, geo.e0, geo.classes);
     const int my_lab = kPerClass ? lj[p] : 0;
-    // One loop over the runs of entries (a run: the cells of one row of one class that the box
-    // reaches), a step of it either takes an entry or moves on to the next run: the lanes of a
-    // wave then need as many steps as the busiest lane has entries and runs, not the sum over the
-    // runs of the busiest lane in each.
-    int c = c_lo - 1, iy = 0, iy1 = -1, ix0 = 0, ix1 = 0, nx = 0, base = 0;
-    unsigned e = 0, e_end = 0;
-    for (;;) {
-      if (e < e_end) {
-        const int q = s_item[e];
-        e += kHashShare;
-        const float4 b = s_hbox[q];
-        const float area_b = (b.z - b.x) * (b.w - b.y);
-        // the smaller area owns the pair (equal areas: the lower rank)
-        const bool owned = area_b > area || (area_b == area && q > p);
-        const float cx = (b.x + b.z) * 0.5f, cy = (b.y + b.w) * 0.5f;
-        if (!owned || area_b > a_max || cx < x_lo || cx > x_hi || cy < y_lo || cy > y_hi) continue;
-        if (kPerClass && lj[q] != my_lab) continue;
-        const float w = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
-        const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
-        const float inter = w * h;
-        if (nms_hit_exact(inter, (area + area_b) - inter, thresh)) {
-          const int first = min(p, q), later = max(p, q);
-          const int word = first >> 6;
-          atomicOr(&mj[(size_t)word * box_stride + later], 1ull << (first & 63));
-          atomicOr(&nj[(size_t)later * nzw + (word >> 6)], 1ull << (word & 63));
-        }
-        continue;
+    // The runs of entries the box reaches (a run: the consecutive cells of one row of one class),
+    // numbered through both classes.
+    int first[2], span[2], pitch[2], rows[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = k ? c_hi : c_lo;
+      const float inv = s_inv[c];
+      const int nx = s_nx[c], ny = s_ny[c];
+      const int ix0 = min(max((int)(x_lo * inv), 0), nx - 1), ix1 = min(max((int)(x_hi * inv), 0), nx - 1);
+      const int iy0 = min(max((int)(y_lo * inv), 0), ny - 1), iy1 = min(max((int)(y_hi * inv), 0), ny - 1);
+      first[k] = s_base[c] + iy0 * nx + ix0;
+      span[k] = ix1 - ix0 + 1;
+      pitch[k] = nx;
+      rows[k] = iy1 - iy0 + 1;
+    }
+    if (c_hi == c_lo) rows[1] = 0;
+    const int runs = rows[0] + rows[1];
+    // The entries of the runs are walked as one sequence, kHashRuns runs at a time: where the
+    // runs start and how many entries come before each go to registers first (independent reads),
+    // then entry t of the sequence is found by compares alone, and the owner's threads take
+    // every kHashShare-th entry.  So the lanes of a wave step in unison however the entries are
+    // spread over the runs, and a lane's number of steps is its owner's entries over kHashShare.
+    auto test = [&](const float4 b, const int q) {
+      const float area_b = (b.z - b.x) * (b.w - b.y);
+      // the smaller area owns the pair (equal areas: the lower rank)
+      const bool owned = area_b > area || (area_b == area && q > p);
+      const float cx = (b.x + b.z) * 0.5f, cy = (b.y + b.w) * 0.5f;
+      if (!owned || area_b > a_max || cx < x_lo || cx > x_hi || cy < y_lo || cy > y_hi) return;
+      if (kPerClass && lj[q] != my_lab) return;
+      const float w = fmaxf(0.0f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+      const float h = fmaxf(0.0f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+      const float inter = w * h;
+      if (nms_hit_exact(inter, (area + area_b) - inter, thresh)) {
+        const int first = min(p, q), later = max(p, q);
+        const int word = first >> 6;
+        atomicOr(&mj[(size_t)word * box_stride + later], 1ull << (first & 63));
+        atomicOr(&nj[(size_t)later * nzw + (word >> 6)], 1ull << (word & 63));
       }
-      if (++iy > iy1) {                 // next class
-        if (++c > c_hi) break;
-        const float inv = s_inv[c];
-        nx = s_nx[c];
-        base = s_base[c];
-        ix0 = min(max((int)(x_lo * inv), 0), nx - 1);
-        ix1 = min(max((int)(x_hi * inv), 0), nx - 1);
-        iy = min(max((int)(y_lo * inv), 0), s_ny[c] - 1);
-        iy1 = min(max((int)(y_hi * inv), 0), s_ny[c] - 1);
+    };
+    for (int r0 = 0; r0 < runs; r0 += kHashRuns) {
+      unsigned shift[kHashRuns], before[kHashRuns + 1];       // entry t of run k is s_cbox[t + shift[k]]
+      before[0] = 0u;
+#pragma unroll
+      for (int k = 0; k < kHashRuns; ++k) {
+        const int r = r0 + k;
+        const bool real = r < runs, hi = r >= rows[0];
+        // (selects and 24-bit products: no branches among the reads)
+        const int row = hi ? r - rows[0] : r;
+        int at = (hi ? first[1] : first[0]) + __mul24(row, hi ? pitch[1] : pitch[0]);
+        at = real ? at : 0;
+        const unsigned from = s_off[at], to = s_off[at + (hi ? span[1] : span[0])];
+        shift[k] = from - before[k];
+        before[k + 1] = before[k] + (real ? to - from : 0u);
       }
-      // the cells of a row are consecutive: one run of entries from the first cell's start to
-      // the last cell's end
-      const int row = base + iy * nx;
-      e = s_off[row + ix0] + sub;
-      e_end = s_off[row + ix1 + 1];
+      const unsigned all = before[kHashRuns];
+      for (unsigned t = sub; t < all; t += kHashShare * RH_HASH_UNROLL) {
+        unsigned e = t + shift[0];
+#pragma unroll
+        for (int k = 1; k < kHashRuns; ++k) e = t >= before[k] ? t + shift[k] : e;
+#if RH_HASH_UNROLL == 2
+        // two entries a step, both requested before either is looked at
+        const unsigned t2 = t + kHashShare;
+        const bool two = t2 < all;
+        unsigned e2 = t2 + shift[0];
+#pragma unroll
+        for (int k = 1; k < kHashRuns; ++k) e2 = t2 >= before[k] ? t2 + shift[k] : e2;
+        e2 = two ? e2 : e;
+        const float4 b0 = s_cbox[e], b1 = s_cbox[e2];
+        const int q0 = s_rank[e], q1 = s_rank[e2];
+        test(b0, q0);
+        if (two) test(b1, q1);
+#else
+        test(s_cbox[e], s_rank[e]);
+#endif
+      }
     }
   }
 }
@@ -2578,7 +2641,7 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
 // Geometry of the centre hash for boxes inside [0, width] x [0, height]; false when the hash
 // form does not apply (the cluster form then runs).
 static bool hash_geometry(const NmsPlan& p, float thresh, float width, float height, HashGeom* out) {
-  if (!RH_PAIR_HASH || !(thresh >= 0.5f) || !(thresh < 1e30f) || p.box_cap > 8 * kHashThreads) return false;
+  if (!RH_PAIR_HASH || !(thresh >= 0.5f) || !(thresh < 1e30f) || p.box_cap > kHashMaxBoxes) return false;
   if (!(width >= 1.0f) || !(height >= 1.0f) || !(width <= 16384.0f) || !(height <= 16384.0f)) return false;
   HashGeom g{};
   g.e0 = 8;
@@ -2616,7 +2679,7 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
   if (hash_geometry(p, thresh, width, height, &geo)) {
     int cus = 0;
     if (int e = compute_units(&cus)) return e;
-    const int per_image = std::max(1, std::min(16, cus / p.batch));
+    const int per_image = std::max(1, std::min(8192 / kHashThreads, cus / p.batch));
     const size_t lds = hash_lds_bytes(p.box_cap, geo.cells);
     auto kern = per_class ? nms_pairs_hash_kernel<true> : nms_pairs_hash_kernel<false>;
     if (int e = allow_lds(kern, lds)) return e;

@@ -1242,6 +1242,14 @@ def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
             else:                # twice the area, the smaller box inside: IoU = 1/2 from the area bound
                 b = [x, y, x + bw, y + 2 * bh * (1.0 + rng.choice([-1, 0, 1]) * 1e-7)]
             boxes += [a, b]
+        # areas a hair under a power of two (the edge of an area bin) with a partner half as large
+        # again, so in the next bin
+        for i in range(400):
+            side = 2.0 ** rng.integers(3, 7)
+            bw, bh = side * (1 - 3e-6) * rng.choice([1, 2]), side
+            x, y = rng.uniform(0, min(w, 1300) - 300), rng.uniform(0, h - 300)
+            grow = rng.uniform(1.3, 1.9)
+            boxes += [[x, y, x + bw, y + bh], [x, y, x + bw, y + bh * grow]]
         boxes = np.asarray(boxes, np.float32)
     elif case == "one_spot":
         k = 3500
