@@ -1881,10 +1881,10 @@ __global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restric
 // centre rule) are dropped; the rest get torchvision's float32 division.
 // A box without area (or with a NaN coordinate) is in no cell and owns nothing: its IoU with
 // anything is 0 or NaN, never above a threshold.
-// 608 px, 8 images of ~2 000 boxes: 11.6 us (5.3 of them launch + table) against 15.1 us for
+// 608 px, 16 images of ~2 000 boxes: 11.3 us (5.3 of them launch + table) against 15.1 us for
 // nms_pairs_kernel; the walk with one loop per run 13.1, with the boxes looked up through their
 // ranks 13.6, with the runs dealt out to the four threads 13.6, two / eight threads per owner
-// 13.8 / 12.4, 1024-thread workgroups 13.8.
+// 13.8 / 12.4, 1024-thread workgroups 13.8; runs taken eight / four at a time 11.6 / 11.8.
 // ---------------------------------------------------------------------------
 #ifndef RH_HASH_THREADS
 #define RH_HASH_THREADS 512
@@ -1892,15 +1892,8 @@ __global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restric
 constexpr int kHashThreads = RH_HASH_THREADS;
 constexpr int kHashMaxBoxes = 4096;
 constexpr int kHashMaxClasses = 20;
-#ifndef RH_HASH_SHARE
-#define RH_HASH_SHARE 4
-#endif
-constexpr int kHashShare = RH_HASH_SHARE;           // threads per owner
-#ifndef RH_HASH_UNROLL
-#define RH_HASH_UNROLL 1
-#endif
 #ifndef RH_HASH_RUNS
-#define RH_HASH_RUNS 8
+#define RH_HASH_RUNS 6
 #endif
 constexpr int kHashRuns = RH_HASH_RUNS;             // runs of entries taken together
 struct HashGeom {
@@ -1938,6 +1931,7 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
   const int j = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float4* bj = sbox + (size_t)j * box_stride;
+  RH_TL(1, 0);
   // the boxes are requested first of all (rows past the list's end are read and not used)
   constexpr int kPer = kHashMaxBoxes / kHashThreads;
   float4 mine[kPer];
@@ -1973,6 +1967,7 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
     }
   }
   __syncthreads();
+  RH_TL(1, 1);
   // exclusive prefix over the cells' counts, in place: a run of cells per thread, the runs'
   // totals by wave scans
   {
@@ -2010,16 +2005,23 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
     if (p < box_stride) s_where[p] = (unsigned short)at;
   }
   __syncthreads();
+  RH_TL(1, 2);
 
   // ---- the owners of this workgroup: ranks g, g + G, .. (by rank and not by place in the table:
-  // the order inside a cell differs from workgroup to workgroup), kHashShare threads each
+  // the order inside a cell differs from workgroup to workgroup)
   const int G = gridDim.x, g = blockIdx.x;
-  const unsigned sub = tid & (kHashShare - 1);
   u64* mj = mask + (size_t)j * box_stride * wstride;
   u64* nj = nz + (size_t)j * box_stride * nzw;
   const int* lj = kPerClass ? slabel + (size_t)j * box_stride : nullptr;
-  for (int i = tid / kHashShare;; i += kHashThreads / kHashShare) {
-    const int p = g + i * G;
+  // `share` threads per owner (a constant of each instance: with the number in a register the
+  // kernel took 0.4 us longer)
+  auto query = [&](auto share_constant) {
+  constexpr int share = decltype(share_constant)::value;
+  constexpr int groups = kHashThreads / share;        // owners per pass; threads past groups * share idle
+  const int group = tid / share;
+  const unsigned sub = tid - group * share;
+  for (int i = group;; i += groups) {
+    const int p = group < groups ? g + i * G : K;
     if (__ballot(p < K) == 0ull) break;
     if (p >= K) continue;
     const unsigned own = s_where[p];
@@ -2059,8 +2061,8 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
     // The entries of the runs are walked as one sequence, kHashRuns runs at a time: where the
     // runs start and how many entries come before each go to registers first (independent reads),
     // then entry t of the sequence is found by compares alone, and the owner's threads take
-    // every kHashShare-th entry.  So the lanes of a wave step in unison however the entries are
-    // spread over the runs, and a lane's number of steps is its owner's entries over kHashShare.
+    // every share-th entry.  So the lanes of a wave step in unison however the entries are
+    // spread over the runs, and a lane's number of steps is its owner's entries over the share.
     auto test = [&](const float4 b, const int q) {
       const float area_b = (b.z - b.x) * (b.w - b.y);
       // the smaller area owns the pair (equal areas: the lower rank)
@@ -2094,28 +2096,24 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
         before[k + 1] = before[k] + (real ? to - from : 0u);
       }
       const unsigned all = before[kHashRuns];
-      for (unsigned t = sub; t < all; t += kHashShare * RH_HASH_UNROLL) {
+      for (unsigned t = sub; t < all; t += share) {
         unsigned e = t + shift[0];
 #pragma unroll
         for (int k = 1; k < kHashRuns; ++k) e = t >= before[k] ? t + shift[k] : e;
-#if RH_HASH_UNROLL == 2
-        // two entries a step, both requested before either is looked at
-        const unsigned t2 = t + kHashShare;
-        const bool two = t2 < all;
-        unsigned e2 = t2 + shift[0];
-#pragma unroll
-        for (int k = 1; k < kHashRuns; ++k) e2 = t2 >= before[k] ? t2 + shift[k] : e2;
-        e2 = two ? e2 : e;
-        const float4 b0 = s_cbox[e], b1 = s_cbox[e2];
-        const int q0 = s_rank[e], q1 = s_rank[e2];
-        test(b0, q0);
-        if (two) test(b1, q1);
-#else
         test(s_cbox[e], s_rank[e]);
-#endif
       }
     }
   }
+  };
+  // Four threads per owner, eight when the workgroup has threads enough for that.  (The code of
+  // every instance costs the kernel time, it seems in instruction fetches: with instances for
+  // three, two and one thread as well -- which save a workgroup the second pass when it has a
+  // few owners more than 128 -- the kernel took 12.2 instead of 11.6 us; the prefix kept in
+  // registers between its two passes, 16 unrolled cells a thread, cost what it saved.)
+  const int owners = K > g ? (K - g + G - 1) / G : 0;
+  if (owners <= kHashThreads / 8) query(std::integral_constant<int, 8>{});
+  else query(std::integral_constant<int, 4>{});
+  RH_TL(1, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -2642,6 +2640,9 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
 // form does not apply (the cluster form then runs).
 static bool hash_geometry(const NmsPlan& p, float thresh, float width, float height, HashGeom* out) {
   if (!RH_PAIR_HASH || !(thresh >= 0.5f) || !(thresh < 1e30f) || p.box_cap > kHashMaxBoxes) return false;
+  // short lists: the table costs more than the cluster form's tests (four 1024 px images, the
+  // best 1 000 boxes of each: 7.5 against 6.8 us)
+  if (p.box_cap < 1536) return false;
   if (!(width >= 1.0f) || !(height >= 1.0f) || !(width <= 16384.0f) || !(height <= 16384.0f)) return false;
   HashGeom g{};
   g.e0 = 8;
@@ -2679,7 +2680,9 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
   if (hash_geometry(p, thresh, width, height, &geo)) {
     int cus = 0;
     if (int e = compute_units(&cus)) return e;
-    const int per_image = std::max(1, std::min(8192 / kHashThreads, cus / p.batch));
+    // (workgroups per image, 608 px, ~2 000 boxes, 8 images: 16: 10.9 us, 32 or more: 9.2; one image:
+    // 16: 10.2, 32: 8.6, 64: 8.1)
+    const int per_image = std::max(1, std::min(64, cus / p.batch));
     const size_t lds = hash_lds_bytes(p.box_cap, geo.cells);
     auto kern = per_class ? nms_pairs_hash_kernel<true> : nms_pairs_hash_kernel<false>;
     if (int e = allow_lds(kern, lds)) return e;

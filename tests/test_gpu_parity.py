@@ -1225,7 +1225,7 @@ def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
     if case == "threshold":
         thr = 0.5
         boxes = []
-        for i in range(1700):
+        for i in range(1500):                # (3 800 boxes in all: the list fits the default room)
             bw, bh = rng.uniform(8, 100), rng.uniform(8, 100)
             x, y = rng.uniform(0, min(w, 1300) - 110), rng.uniform(0, h - 110)
             f = thr * (1.0 + rng.choice([-3, -1, 0, 1, 3]) * 6e-8 * rng.integers(0, 3))
@@ -1285,7 +1285,7 @@ def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
     assert kept <= kept_pc < n
     check_post_hw(rh, cls, reg, anc, hw, iou_thresh=0.75)
     check_post_hw(rh, cls, reg, anc, hw, iou_thresh=0.45)  # below one half: the cluster form
-    check_post_hw(rh, cls, reg, anc, hw, pre_nms_topk=700, mode="per_class")
+    check_post_hw(rh, cls, reg, anc, hw, pre_nms_topk=2000, mode="per_class")
 
 
 def test_postprocess_topk_preselection(rh):

@@ -21,7 +21,8 @@ import retinahead as rh  # noqa: E402
 from retinahead import functional as F  # noqa: E402
 
 KERNELS = {0: ("sort_rank", ["start", "count pass", "list in LDS", "ranks counted", "end", "bins laid out", "bins filled"]),
-           1: ("nms_pairs", ["start", "counters read", "own cluster loaded", "end"]),
+           1: ("nms_pairs (hash form: boxes binned / table built)",
+               ["start", "counters read", "own cluster loaded", "end"]),
            2: ("nms_resolve", ["start", "words loaded", "rounds done", "end", "round 1 done", None,
                                "round 2 done", "round 3 done"])}
 BLOCKS, SLOTS = 8192, 12
