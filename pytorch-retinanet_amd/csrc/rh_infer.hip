@@ -1873,18 +1873,24 @@ __global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restric
 // chance, the result is a set of bits), which leaves the boxes themselves in cell order, their
 // ranks beside them, and for every rank the place of its box.  Then the workgroup handles its
 // share of the owners (ranks g, g + G, ..: a split by place in the table would differ from
-// workgroup to workgroup), four threads per owner.  The cells of one row of one class that an
-// owner reaches are consecutive, so their entries form one run; the owner's runs (typically
-// four, two or three rows in each of two classes) are walked as a single sequence of which the
-// four threads take every fourth entry.  Candidates that own nothing, lie outside the area
+// workgroup to workgroup), four or eight threads per owner.  The cells of one row of one class
+// that an owner reaches are consecutive, so their entries form one run; the owner's runs
+// (typically four, two or three rows in each of two classes) are walked as a single sequence
+// of which its threads take every fourth (eighth) entry.  Candidates that own nothing, lie outside the area
 // window or have their centre outside the owner's box (with the slack of nms_pairs_kernel's
 // centre rule) are dropped; the rest get torchvision's float32 division.
 // A box without area (or with a NaN coordinate) is in no cell and owns nothing: its IoU with
 // anything is 0 or NaN, never above a threshold.
-// 608 px, 16 images of ~2 000 boxes: 11.3 us (5.3 of them launch + table) against 15.1 us for
-// nms_pairs_kernel; the walk with one loop per run 13.1, with the boxes looked up through their
-// ranks 13.6, with the runs dealt out to the four threads 13.6, two / eight threads per owner
-// 13.8 / 12.4, 1024-thread workgroups 13.8; runs taken eight / four at a time 11.6 / 11.8.
+// 608 px, 16 images of ~2 000 boxes: 11.3 us against 15.1 us for nms_pairs_kernel.  Larger
+// workgroups are faster alone (640 / 768 / 1024 threads: 10.8 / 10.6 / 10.2 us, the call on
+// one stream 88.6 instead of 90.2 us: the table allows one workgroup per compute unit either
+// way, and 256 groups of four threads take a full list in one pass) but cost the pipelined
+// form a tenth of its rate (three batches in flight 70.5 instead of 64.2 us per batch from 640
+// threads on: a workgroup of more than two waves per SIMD has to wait for room among the other
+// batches' score-scan waves), so 512 it is.  All with 512 threads: the walk with one loop per
+// run 13.1, with the boxes looked up through their ranks 13.6, with the runs dealt out to the
+// four threads 13.6, two / eight threads for every owner 13.8 / 12.4; runs taken eight / four
+// at a time 11.6 / 11.8.
 // ---------------------------------------------------------------------------
 #ifndef RH_HASH_THREADS
 #define RH_HASH_THREADS 512
@@ -1933,7 +1939,7 @@ __global__ __launch_bounds__(kHashThreads) void nms_pairs_hash_kernel(
   const float4* bj = sbox + (size_t)j * box_stride;
   RH_TL(1, 0);
   // the boxes are requested first of all (rows past the list's end are read and not used)
-  constexpr int kPer = kHashMaxBoxes / kHashThreads;
+  constexpr int kPer = (kHashMaxBoxes + kHashThreads - 1) / kHashThreads;
   float4 mine[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) mine[u] = bj[min(tid + u * kHashThreads, box_stride - 1)];

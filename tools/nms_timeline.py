@@ -62,9 +62,13 @@ def main():
         if k in (1, 2):
             a, b = (2, 3) if k == 1 else (0, 2)
             ok = (t[:, 9] > 0) & (t[:, b] > t[:, a])
-            ghz = (t[ok, 9] - t[ok, 8]) / ((t[ok, b] - t[ok, a]) * 10.0)
-            print(f"   shader clock while it ran: median {np.median(ghz):.2f} GHz (min {ghz.min():.2f}, max {ghz.max():.2f})")
-        if k == 1:
+            if ok.any():
+                ghz = (t[ok, 9] - t[ok, 8]) / ((t[ok, b] - t[ok, a]) * 10.0)
+                print(f"   shader clock while it ran: median {np.median(ghz):.2f} GHz (min {ghz.min():.2f}, max {ghz.max():.2f})")
+        if k == 1 and not (t[:, 9] > 0).any():       # the hash form stamps the four marks only
+            walk = (t[:, 3] - t[:, 2]) / 100.0
+            print(f"   walk of the owners (wave 0): median {np.median(walk):.2f}  p90 {np.percentile(walk, 90):.2f}  max {walk.max():.2f} us")
+        elif k == 1:
             done = t[t[:, 3] > 0]
             dur = (done[:, 3] - done[:, 2]) / 100.0
             print(f"   work per workgroup (wave 0): median {np.median(dur):.2f} max {dur.max():.2f} us;"
