@@ -27,7 +27,8 @@ def train(fn, launches=20, reps=10):
     return ms * 1e3
 print(os.path.basename(L.LIB_PATH), "kept", int(res["counts"][0].sum()))
 print(f"  sort alone {train(lambda: post(res, L.POST_SORT)):.1f} us   nms alone {train(lambda: post(res, L.POST_NMS)):.1f} us   whole call {train(lambda: post(res)):.1f} us")
-streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+NS = int(os.environ.get("RH_STREAMS", "3"))       # batches in flight
+streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
 outs = []
 for s in streams:
     with torch.cuda.stream(s):
@@ -42,7 +43,7 @@ def run(k):
 run(150)
 tr = []
 for _ in range(5):
-    t1 = time.perf_counter(); run(100); tr.append((time.perf_counter() - t1) / 300 * 1e6)
-print("  three in flight:", [round(x, 1) for x in tr])
+    t1 = time.perf_counter(); run(100); tr.append((time.perf_counter() - t1) / (100 * NS) * 1e6)
+print(f"  {NS} in flight:" if NS != 3 else "  three in flight:", [round(x, 1) for x in tr])
 for k in ("scores", "labels", "boxes", "counts"):
     assert torch.equal(outs[0][k], ref[k]), k
