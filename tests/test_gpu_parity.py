@@ -1218,7 +1218,7 @@ def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
     on and images of moderate size bins the boxes by area and centre and otherwise (the wide
     image here) compares clusters of the ranked list: pairs whose IoU is the threshold give or take
     an ulp with a centre on the partner's edge; thousands of boxes around one spot (one bin holds
-    them all); thin, tiny, empty and image-sized boxes."""
+    them all); thin, tiny, empty and image-sized boxes, and boxes that the clip turns inside out."""
     h, w = hw
     rng = np.random.default_rng(len(case) + h)
     c = 4
@@ -1261,7 +1261,7 @@ def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
         k = 3000
         ctr = rng.uniform(0, 1, (k, 2)) * [min(w, 1300), h]
         wh = np.empty((k, 2))
-        kinds = rng.integers(0, 6, k)
+        kinds = rng.integers(0, 7, k)
         wh[kinds == 0] = rng.uniform(0.05, 0.9, ((kinds == 0).sum(), 2))            # under a pixel
         wh[kinds == 1] = np.stack([rng.uniform(1, 3, (kinds == 1).sum()),
                                    rng.uniform(300, 900, (kinds == 1).sum())], 1)   # thin, tall
@@ -1270,6 +1270,8 @@ def test_postprocess_pair_search_on_hard_box_sets(rh, case, hw):
         wh[kinds == 3] = rng.uniform(700, 2600, ((kinds == 3).sum(), 2))            # clipped to the image
         wh[kinds == 4] = rng.uniform(10, 60, ((kinds == 4).sum(), 2))
         wh[kinds == 5] = 0.0                                                        # empty
+        wh[kinds == 6] = rng.uniform(10, 60, ((kinds == 6).sum(), 2))               # outside the image: clipped
+        ctr[kinds == 6] = -rng.uniform(80, 300, ((kinds == 6).sum(), 2))            # to a negative width and height
         ctr[kinds == 1, 0] = np.round(ctr[kinds == 1, 0] / 40) * 40                 # so that they do overlap
         ctr[kinds == 2, 1] = np.round(ctr[kinds == 2, 1] / 40) * 40
         boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
