@@ -254,9 +254,11 @@ int rh_match_detections(const float* det_boxes, const int64_t* det_labels, const
   RH_REQUIRE(aligned16(det_boxes), RH_EALIGN, "det_boxes must be 16-byte aligned");
   RH_REQUIRE(m <= 64 * 1024, RH_ESHAPE, "m=%d: at most 65536 annotation rows per image", m);
   const size_t lds = (size_t)(m > 0 ? m : 1);
+  // (always the kernel's ceiling, m's limit above: a per-launch value could be lowered by another
+  // host thread between this call and the launch)
   if (lds > 48 * 1024)
     RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(match_detections_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   hipLaunchKernelGGL(match_detections_kernel, dim3(batch), dim3(64), lds, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(det_boxes),
                      reinterpret_cast<const long long*>(det_labels), det_count, annotations, tp, d, m,

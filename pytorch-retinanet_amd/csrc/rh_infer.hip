@@ -1897,6 +1897,7 @@ __global__ __launch_bounds__(kThreads) void nz_dense_kernel(const int* __restric
 #endif
 constexpr int kHashThreads = RH_HASH_THREADS;
 constexpr int kHashMaxBoxes = 4096;
+constexpr size_t kHashLdsLimit = 150 * 1024;        // dynamic LDS of the table, at most
 constexpr int kHashMaxClasses = 20;
 #ifndef RH_HASH_RUNS
 #define RH_HASH_RUNS 6
@@ -2157,6 +2158,7 @@ struct SweepOut {
 
 constexpr int kResolveWaves = 16;
 constexpr int kResolveThreads = 64 * kResolveWaves;
+constexpr size_t kResolveLdsLimit = 160 * 1024;     // the whole LDS of a compute unit
 
 __host__ __device__ inline size_t resolve_lds_bytes(int wstride) {
   // lo and hi bitmaps, kept-before-chunk counts, three "still open" flags
@@ -2492,9 +2494,9 @@ static NmsPlan make_plan(int batch, long long cap, int topk) {
 
 // Limits of the NMS stages, checked before anything is launched.
 static int check_plan(const NmsPlan& p) {
-  RH_REQUIRE(resolve_lds_bytes(p.wstride) <= 160 * 1024, RH_ESHAPE,
+  RH_REQUIRE(resolve_lds_bytes(p.wstride) <= kResolveLdsLimit, RH_ESHAPE,
              "%d boxes per image exceed the LDS bitmaps of the NMS (at most %d): lower cand_cap or "
-             "set pre_nms_topk", p.box_cap, (int)((160 * 1024 - 4) / 20) * 64);
+             "set pre_nms_topk", p.box_cap, (int)((kResolveLdsLimit - 16) / 20) * 64);
   return RH_OK;
 }
 
@@ -2560,12 +2562,17 @@ static SortOut sort_out(const NmsPlan& p, const PostWorkspace& w) {
   return so;
 }
 
-// Kernels that use more dynamic LDS than the default limit must opt in.
+// Kernels that use more dynamic LDS than the default limit must opt in.  The limit is a property
+// of the kernel, not of the launch, so it is always set to `ceiling`, the most the kernel is
+// ever launched with: set to each launch's own size, a host thread with a small launch could
+// lower it between another thread's call here and that thread's larger launch.
 template <typename Kernel>
-static int allow_lds(Kernel kernel, size_t bytes) {
+static int allow_lds(Kernel kernel, size_t bytes, size_t ceiling) {
+  RH_REQUIRE(bytes <= ceiling, RH_ESHAPE, "%zu bytes of LDS asked for, the kernel's limit is %zu", bytes,
+             ceiling);
   if (bytes > 48 * 1024)
     RH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ceiling));
   return RH_OK;
 }
 
@@ -2600,7 +2607,7 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
       from.list_count = w.sel_count;
     }
     const size_t lds = rank_lds_bytes(p.cap);
-    if (int e = allow_lds(sort_rank_kernel, lds)) return e;
+    if (int e = allow_lds(sort_rank_kernel, lds, rank_lds_bytes(kRankMax))) return e;
     // Blocks per image: as many as the capacity could need at kRankKpl clusters each, but no
     // more than gives every compute unit one block -- a second block on a unit (even one that
     // finds nothing to rank) slows the first: 16 images x 32 blocks, half of them without work,
@@ -2620,7 +2627,7 @@ static int launch_sort(const NmsPlan& p, const PostWorkspace& w, int topk, const
   }
   if (p.key_stride <= kLdsSortMax) {
     const size_t lds = (size_t)p.key_stride * sizeof(u64) + 16;
-    if (int e = allow_lds(sort_lds_kernel, lds)) return e;
+    if (int e = allow_lds(sort_lds_kernel, lds, (size_t)kLdsSortMax * sizeof(u64) + 16)) return e;
     hipLaunchKernelGGL(sort_lds_kernel, dim3(p.batch), dim3(kSortThreads), lds, s, w.counters, p.batch,
                        p.cap, topk, src, so);
     RH_CHECK_LAUNCH("sort_lds_kernel");
@@ -2665,7 +2672,7 @@ static bool hash_geometry(const NmsPlan& p, float thresh, float width, float hei
     cells += g.nx[c] * g.ny[c];
   }
   g.cells = cells;
-  if (cells >= 65535 || hash_lds_bytes(p.box_cap, cells) > 150 * 1024) return false;
+  if (cells >= 65535 || hash_lds_bytes(p.box_cap, cells) > kHashLdsLimit) return false;
   *out = g;
   return true;
 }
@@ -2691,7 +2698,7 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
     const int per_image = std::max(1, std::min(64, cus / p.batch));
     const size_t lds = hash_lds_bytes(p.box_cap, geo.cells);
     auto kern = per_class ? nms_pairs_hash_kernel<true> : nms_pairs_hash_kernel<false>;
-    if (int e = allow_lds(kern, lds)) return e;
+    if (int e = allow_lds(kern, lds, kHashLdsLimit)) return e;
     hipLaunchKernelGGL(kern, dim3(per_image, p.batch), dim3(kHashThreads), lds, s, w.sbox, w.slabel, keff,
                        w.mask, w.nz, p.box_cap, p.wstride, p.nzw, thresh, geo);
     RH_CHECK_LAUNCH("nms_pairs_hash_kernel");
@@ -2742,7 +2749,7 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
               : p.box_cap <= 2048 ? nms_resolve_kernel<2>
               : p.box_cap <= 4096 ? nms_resolve_kernel<4>
                                   : nms_resolve_kernel<0>;
-  if (int e = allow_lds(kern, lds)) return e;
+  if (int e = allow_lds(kern, lds, kResolveLdsLimit)) return e;
   hipLaunchKernelGGL(kern, dim3(p.batch), dim3(kResolveThreads), lds, s, w.keys, w.sbox, w.slabel, keff,
                      w.mask, w.nz, p.key_stride, p.box_cap, p.wstride, p.nzw, out);
   RH_CHECK_LAUNCH("nms_resolve_kernel");

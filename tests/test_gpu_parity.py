@@ -1411,6 +1411,45 @@ def test_two_host_threads_on_their_own_streams(rh):
     assert not errors, errors
 
 
+def test_two_host_threads_with_lists_of_different_room(rh):
+    """Kernels that use more than 48 KB of dynamic LDS opt in through an attribute of the kernel,
+    which every host thread sets before its launch: set to each launch's own size, the thread with
+    the smaller lists could lower it just before the other thread's larger launch, which then
+    fails.  Two threads post-process at once with room for 4 096 and 8 192 candidates (57 and
+    112 KB in the rank sort); every call must succeed and give the single-thread result."""
+    import threading
+    F = rh.functional
+    cls, reg, anc = infer_batch(61, 2, 192, 8, mu=-4.6)
+    c, r, a = dev(cls), dev(reg), dev(anc)
+    caps = [4096, 8192]
+    want = [F.postprocess_raw(c, r, a, 192, 192, cand_cap=cap) for cap in caps]
+    want = [{k: v.clone() for k, v in w.items() if torch.is_tensor(v)} for w in want]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(300):
+                    p = F.postprocess_raw(c, r, a, 192, 192, cand_cap=caps[i])
+                st.synchronize()
+                kept = p["counts"][0]
+                if not (torch.equal(p["counts"], want[i]["counts"]) and
+                        all(torch.equal(p["boxes"][b, :int(kept[b])], want[i]["boxes"][b, :int(kept[b])])
+                            for b in range(2))):
+                    errors.append(f"thread {i}: results differ")
+        except Exception as e:                       # surfaced in the main thread below
+            errors.append(f"thread {i}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors
+
+
 def test_zz_tolerance_floors_report(rh):
     """Runs after the gradient tests of this file, of the full-size configurations and of the
     two-rank runs (file and name order) and states what their absolute
