@@ -1099,12 +1099,13 @@ __device__ __forceinline__ void rank_pass(const int c0, const bool writes_counte
           box = src.boxes[idx];
         }
         so.sbox[o] = box;
-        so.cbox[q] = box;
+        if (so.cbox) so.cbox[q] = box;
         so.slabel[o] = s_lab[p];
         for (int g = 0; g < so.nzw; ++g) so.nz[o * so.nzw + g] = 0ull;
       }
-      so.cinfo[q] = make_int4(passed ? rk : -1, s_lab[p],
-                              __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
+      if (so.cbox)
+        so.cinfo[q] = make_int4(passed ? rk : -1, s_lab[p],
+                                __float_as_int((box.z - box.x) * (box.w - box.y)), 0);
     }
     // each 64 list entries are one cluster of the pair kernel
     if (cluster < so.clusters) {
@@ -2470,6 +2471,8 @@ struct NmsPlan {
   bool ranked;      // the rank sort runs: list-order arrays exist
   bool select;      // a top-k pre-selection cuts the candidate lists down first
   int clusters;     // clusters of 64 list entries (ranked) or 64 ranks (not ranked)
+  bool hash;        // the pair search will be the centre hash: the rank sort leaves out what only
+                    // the cluster form reads (boxes and ranks in list order, cluster summaries)
 };
 
 static NmsPlan make_plan(int batch, long long cap, int topk) {
@@ -2489,6 +2492,7 @@ static NmsPlan make_plan(int batch, long long cap, int topk) {
   // slower gather -- 608 px, 2000 candidates: 108 against 100 us alone, 74.6 against 69.7 us per
   // batch with four in flight.)
   p.clusters = ((p.ranked ? p.cap : p.box_cap) + 63) / 64;
+  p.hash = false;     // (set by the callers that know the image's size: hash_geometry())
   return p;
 }
 
@@ -2549,7 +2553,7 @@ static SortOut sort_out(const NmsPlan& p, const PostWorkspace& w) {
   so.sbox = w.sbox;
   so.slabel = w.slabel;
   so.nz = w.nz;
-  so.cbox = p.ranked ? w.cbox : nullptr;
+  so.cbox = p.ranked && !p.hash ? w.cbox : nullptr;    // (null: the rank sort writes neither cbox nor cinfo)
   so.cinfo = w.cinfo;
   so.csum = w.csum;
   so.mask = w.mask;
@@ -2558,7 +2562,7 @@ static SortOut sort_out(const NmsPlan& p, const PostWorkspace& w) {
   so.list_stride = p.cap;
   so.nzw = p.nzw;
   so.wstride = p.wstride;
-  so.clusters = p.clusters;
+  so.clusters = p.ranked && p.hash ? 0 : p.clusters;   // (0: no cluster summaries)
   return so;
 }
 
@@ -2690,7 +2694,9 @@ static int launch_nms(const NmsPlan& p, const PostWorkspace& w, float thresh, in
     RH_CHECK_LAUNCH("cluster_prepare_kernel");
   }
   HashGeom geo;
-  if (hash_geometry(p, thresh, width, height, &geo)) {
+  if (p.hash) {
+    RH_REQUIRE(hash_geometry(p, thresh, width, height, &geo), RH_EINVAL,
+               "the plan asks for the hash pair search, which these arguments do not allow");
     int cus = 0;
     if (int e = compute_units(&cus)) return e;
     // (workgroups per image, 608 px, ~2 000 boxes, 8 images: 16: 10.9 us, 32 or more: 9.2; one image:
@@ -2950,8 +2956,10 @@ int rh_postprocess(const float* classifications, const float* regressions, const
   RH_REQUIRE(aligned16(anchors) && aligned16(regressions) && aligned16(out_boxes), RH_EALIGN,
              "anchors, regressions and out_boxes must be 16-byte aligned");
   RH_REQUIRE((stages & ~RH_POST_ALL) == 0 && stages != 0, RH_EINVAL, "bad stages mask %d", stages);
-  const NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
+  NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
   if (int e = check_plan(p)) return e;
+  HashGeom unused;
+  p.hash = hash_geometry(p, q->iou_thresh, q->width, q->height, &unused);
   const int total_rows = (int)((long long)batch * n);
   const int num_tiles = (total_rows + kTileRows - 1) / kTileRows;
   const size_t need = carve_post(nullptr, p, num_tiles).bytes;
@@ -3080,8 +3088,10 @@ int rh_postprocess_levels(const float* const* cls_levels, const float* const* re
   const int tiles_per_image = chunks * (kLvlChunk / 64);
   const long long num_tiles = (long long)batch * tiles_per_image;
   RH_REQUIRE(num_tiles < (1ll << 31), RH_ESHAPE, "too many tile lists");
-  const NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
+  NmsPlan p = make_plan(batch, q->cand_cap, q->pre_nms_topk);
   if (int e = check_plan(p)) return e;
+  HashGeom unused;
+  p.hash = hash_geometry(p, q->iou_thresh, q->width, q->height, &unused);
   const size_t need = carve_post(nullptr, p, num_tiles).bytes;
   RH_REQUIRE(workspace && workspace_bytes >= need, RH_EWORKSPACE,
              "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
