@@ -18,6 +18,68 @@ from . import functional as F
 from . import modules
 
 
+def _hip_runtime():
+    """The HIP runtime this process already has loaded (torch's), or None."""
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return None
+    if len(paths) != 1:         # none, or two runtimes mapped: not ours to choose between
+        return None
+    try:
+        return C.CDLL(paths.pop())
+    except OSError:
+        return None
+
+
+_idle_stream_sets = {}      # (device index, n) -> stream sets whose pipeline is gone
+
+
+class _OwnStreams:
+    """``n`` HIP streams created one after the other for pipelines alone.  Streams drawn from torch's
+    pool can share one of HIP's four hardware queues per process -- the pool holds 32 and hands them out
+    in turn, so a process that has used a few dozen streams gives a pipeline a set of which two sit on
+    one queue, and their batches no longer overlap (80-93 instead of 65 us per batch; streams created in
+    a row get queues in a row).  The streams are never destroyed (the caching allocator keeps the
+    handle of the stream a block was allocated on): a pipeline that goes hands its set to the next one.
+    Falls back to the pool where the runtime cannot be reached."""
+
+    def __init__(self, n, device):
+        self.key = (device.index, n)
+        idle = _idle_stream_sets.get(self.key)
+        if idle:
+            self.streams, self.own = idle.pop(), True
+            return
+        self.streams, self.own = [], True
+        hip = _hip_runtime()
+        try:
+            if hip is None:
+                raise OSError("HIP runtime not found")
+            with torch.cuda.device(device):
+                for _ in range(n):
+                    h = C.c_void_p()
+                    if hip.hipStreamCreateWithFlags(C.byref(h), 1) != 0 or not h.value:    # 1: non-blocking
+                        raise OSError("hipStreamCreateWithFlags failed")
+                    self.streams.append(torch.cuda.ExternalStream(h.value, device=device))
+        except (OSError, AttributeError, RuntimeError):
+            # (streams already created stay unused; nothing is destroyed)
+            self.streams, self.own = [torch.cuda.Stream(device=device) for _ in range(n)], False
+
+    def release(self):
+        if self.own and self.streams:
+            try:
+                for st in self.streams:
+                    st.synchronize()
+                _idle_stream_sets.setdefault(self.key, []).append(self.streams)
+            except Exception:       # interpreter shutdown
+                pass
+        self.streams = []
+
+    def __del__(self):
+        self.release()
+
+
 class Detections(collections.abc.Sequence):
     """A batch's detections, ``[{'boxes','labels','scores'}]`` per image like the list
     ``retinahead.postprocess`` returns, with the per-image views made when asked for (slicing 48
@@ -45,7 +107,7 @@ class PostprocessPipeline:
     as a sequence that makes each image's views on access).
 
     depth: batches that may be in flight (output buffers); streams: HIP streams they are spread
-    over.  Three streams and the default stream have a hardware queue each with HIP's four queues
+    over (created for the pipeline, outside torch's stream pool).  Three streams and the default stream have a hardware queue each with HIP's four queues
     per process: a fourth stream gains 2 % when the queues fall well and loses 5-10 % when two
     streams share one, which is not under the caller's control.  Twice as many slots keep the
     streams fed while the host waits for the oldest batch (608 px, 80 classes, 16 images:
@@ -74,7 +136,8 @@ class PostprocessPipeline:
         if self.kw["mode"] not in ("agnostic", "per_class"):
             raise ValueError("mode must be 'agnostic' or 'per_class'")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
+        self._own = _OwnStreams(streams, self.device)
+        self.streams = self._own.streams
         self.slots = [None] * depth        # per slot: (shape key, device outputs, pinned counts)
         self.pending = collections.deque()
         self.turn = 0

@@ -59,3 +59,31 @@ def test_pipeline_overflow_falls_back_and_limits(rh):
         pipe.submit(dev(cls), dev(reg), dev(anc), (size, size))
     with pytest.raises(TypeError):
         rh.PostprocessPipeline(bogus=1)
+
+
+def test_pipeline_streams_are_its_own_and_are_handed_on(rh):
+    """A pipeline's streams are created for pipelines, one after the other, outside torch's pool of
+    32 (whose streams can share a hardware queue, after which batches no longer overlap); they are
+    never destroyed -- the caching allocator remembers the stream of every block -- but handed to
+    the next pipeline of the same width when theirs is gone."""
+    import gc
+    size, c = 128, 6
+    cls, reg, anc = infer_batch(70, 2, size, c, mu=-4.0)
+    want = rh.postprocess(dev(cls), dev(reg), dev(anc), (size, size))
+    pool = {torch.cuda.Stream().cuda_stream for _ in range(40)}          # the whole pool, and around again
+    pipe = rh.PostprocessPipeline(depth=4, streams=2)
+    first = [s.cuda_stream for s in pipe.streams]
+    assert len(set(first)) == 2 and not (set(first) & pool)
+    for _ in range(6):
+        pipe.submit(dev(cls), dev(reg), dev(anc), (size, size))
+        same_detections(pipe.results(), want)
+    del pipe
+    gc.collect()
+    again = rh.PostprocessPipeline(depth=4, streams=2)
+    assert [s.cuda_stream for s in again.streams] == first
+    other = rh.PostprocessPipeline(depth=3, streams=3)                   # another width: streams of its own
+    assert not (set(s.cuda_stream for s in other.streams) & set(first))
+    for p in (again, other):
+        p.submit(dev(cls), dev(reg), dev(anc), (size, size))
+    for p in (again, other):
+        same_detections(p.results(), want)

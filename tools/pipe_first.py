@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Is the FIRST PostprocessPipeline of a process slower than the later ones, and is it the streams it
-draws?  A fresh process, N pipelines one after the other, each warmed by 100 batches and timed over 400;
-optionally some streams drawn from torch's pool first.  usage: python3 tools/pipe_first.py [streams drawn first]"""
+"""Does a PostprocessPipeline depend on the streams the process has used before it?  A fresh process, five
+pipelines one after the other, each warmed by 100 batches and timed over 400; optionally some streams drawn
+from torch's pool first (RH_USE_DRAWN=1: and used).  With streams from torch's pool, the pipeline that
+came after ~32 used streams ran at 80-93 us per batch instead of 65; with streams of its own, none does.
+usage: python3 tools/pipe_first.py [streams drawn first]"""
 import os
 import sys
 import time
@@ -23,6 +25,11 @@ for i in range(3):
     c, r = bench.synth_infer(np.random.default_rng(3000 + i), 16, n, 80)
     sets.append((torch.from_numpy(c).to(dev), torch.from_numpy(r).to(dev)))
 drawn = [torch.cuda.Stream(device=dev) for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 0)]
+if os.environ.get("RH_USE_DRAWN"):          # ... and used, so that each has a hardware queue
+    from retinahead import functional as F
+    for s_ in drawn:
+        with torch.cuda.stream(s_):
+            F.postprocess_raw(sets[0][0], sets[0][1], anchors, 608, 608)
 torch.cuda.synchronize()
 for trial in range(5):
     pipe = rh.PostprocessPipeline(depth=6, streams=3)
