@@ -1,6 +1,6 @@
 """usage (on the GPU box): python3 tools/check_post_variant.py <lib.so> ...
 Post-processing of a 608 px batch by library variants (tools/build_variant.sh), every image
-against the oracle fed with the device's decoded boxes; prints one verdict per library."""
+against the oracle fed with the device's decoded boxes; prints one line per library."""
 import os
 import subprocess
 import sys
