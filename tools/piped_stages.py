@@ -20,6 +20,7 @@ import retinahead as rh  # noqa: E402
 from retinahead import functional as F  # noqa: E402
 
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+CAP = int(os.environ.get("RH_CAP", "4096"))      # room of the candidate lists
 dev = torch.device("cuda:0")
 anchors = rh.Anchors()(torch.zeros(1, 3, 608, 608, device=dev))
 n = anchors.shape[1]
@@ -31,7 +32,7 @@ streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
 outs = []
 for s, (c, r) in zip(streams, sets):
     with torch.cuda.stream(s):
-        outs.append(F.postprocess_raw(c, r, anchors, 608, 608))
+        outs.append(F.postprocess_raw(c, r, anchors, 608, 608, cand_cap=CAP))
 torch.cuda.synchronize()
 
 
@@ -39,7 +40,7 @@ def run(k, stages):
     for _ in range(k):
         for s, o, (c, r) in zip(streams, outs, sets):
             with torch.cuda.stream(s):
-                F.postprocess_raw(c, r, anchors, 608, 608, out=o, stages=stages)
+                F.postprocess_raw(c, r, anchors, 608, 608, cand_cap=CAP, out=o, stages=stages)
     torch.cuda.synchronize()
 
 
