@@ -58,15 +58,17 @@ for case in range(cases):
     anc = boxes[None]
     thr = float(rng.choice([0.5, 0.5, 0.55, 0.6, 0.7, 0.9]))
     mode = "per_class" if rng.random() < 0.4 else "agnostic"
+    topk = int(rng.integers(1536, k + 1)) if rng.random() < 0.3 else None      # (the best `topk` only)
     dcls, dreg, danc = (torch.from_numpy(x).to(dev) for x in (cls, reg, anc))
-    res = rh.postprocess(dcls, dreg, danc, (h, w), iou_thresh=thr, mode=mode)[0]
+    res = rh.postprocess(dcls, dreg, danc, (h, w), iou_thresh=thr, mode=mode, pre_nms_topk=topk)[0]
     dboxes = rh.ClipBoxes()(rh.BBoxTransform()(danc, dreg), torch.empty(1, 3, h, w, device=dev)).cpu().numpy()
-    s, l, bx = O.postprocess_image(cls[0], reg[0], anc, h, w, boxes=dboxes[0], iou_thresh=thr, mode=mode)
+    s, l, bx = O.postprocess_image(cls[0], reg[0], anc, h, w, boxes=dboxes[0], iou_thresh=thr, mode=mode,
+                                   pre_nms_topk=topk)
     same = (np.array_equal(res["labels"].cpu().numpy(), l) and np.array_equal(res["scores"].cpu().numpy(), s)
             and np.array_equal(res["boxes"].cpu().numpy(), bx))
     if not same:
         bad += 1
-        print(f"case {case}: DIFFERS (kind {kind}, {h}x{w}, k {k}, thr {thr}, {mode}; kept {res['scores'].numel()} want {len(s)})")
+        print(f"case {case}: DIFFERS (kind {kind}, {h}x{w}, k {k}, thr {thr}, {mode}, top-k {topk}; kept {res['scores'].numel()} want {len(s)})")
     if case % 20 == 19:
         print(f"{case + 1} cases, {bad} differ, {time.time() - t0:.0f} s", flush=True)
 print(f"fuzz: {cases} cases, {bad} differ")
